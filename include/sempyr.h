@@ -38,12 +38,25 @@ enum sp_act { SP_ACT_NONE = 0, SP_ACT_LRELU = 1, SP_ACT_RELU = 2, SP_ACT_TANH = 
 
 int sp_version(void);
 
-/* Kernel-selection knobs for tests and A/B measurements (no effect on results beyond fp summation order).
- * value < 0 restores the default (environment variable, then built-in heuristic).
- *   SP_TUNE_CONV_TALL (env SP_CONV_TALL): 0 = never use conv3x3_tall_kernel, 1 = where its tiles fill the chip, 2 = wherever legal
- *   SP_TUNE_IGEMM_DMA (env SP_IGEMM_DMA): 0 = never use the LDS-DMA igemm kernel, 1 = small-spatial 3x3 layers, 2 = everywhere
- *   SP_TUNE_WGRAD_ROWS (env SP_WGRAD_ROWS): 0 = never use the row-walker 3x3 weight-gradient kernel, 1 = wherever legal */
-enum { SP_TUNE_CONV_TALL = 0, SP_TUNE_IGEMM_DMA = 1, SP_TUNE_WGRAD_ROWS = 2, SP_TUNE_COUNT = 3 };
+/* Knobs for tests and A/B measurements.  The library reads NO environment variables: every switch goes through this call
+ * (the Python binding forwards SP_* environment variables of the same names at load time, _lib.py).  value < 0 restores the
+ * built-in default.  Except SP_TUNE_DETERMINISTIC none of them changes results beyond fp summation order.
+ *   SP_TUNE_CONV_TALL        0 = never use conv3x3_tall_kernel, 1 = where its tiles fill the chip (default), 2 / 3 = force the 16- / 8-row form
+ *   SP_TUNE_IGEMM_DMA        0 = never use the LDS-DMA igemm kernel, 1 = small-spatial 3x3 layers (default), 2 = everywhere
+ *   SP_TUNE_WGRAD_ROWS       0 = never use the row-walker 3x3 weight-gradient kernel, 1 = wherever legal (default)
+ *   SP_TUNE_DETERMINISTIC    1 = every floating-point reduction runs in a fixed order (per-split partial slabs + ordered
+ *                            reduce instead of fp32 atomics): bit-identical results run to run; 0 = atomics where they are
+ *                            faster; default (-1): on for SP_F32 storage (the parity mode), off for SP_BF16
+ *   SP_TUNE_SPLITK_TARGET / _MINSTEPS     split-K plan of the small-spatial 3x3 forward / input-gradient layers (640 / 6)
+ *   SP_TUNE_CONV1X1_DIRECT   0 = 1x1 layers on the tiled igemm kernel (default 1: direct kernel)
+ *   SP_TUNE_CONV_SHORT       0 = Cout > 64 layers on the register-staged halo kernel (default 1: 8-row tall kernel)
+ *   SP_TUNE_WGRAD9_BLOCKS, _WGRAD_BLOCKS, _WGRAD_MINSTEPS, _WGRAD_SMALL_M, _WGRAD_K1_TILE64   per-tap weight-gradient plan
+ *   SP_TUNE_WGRAD_ROWS_THIN, _WGRAD_ROWS_BLOCKS, _WGRAD_ROWS_SLABS                            row-walker plan */
+enum { SP_TUNE_CONV_TALL = 0, SP_TUNE_IGEMM_DMA = 1, SP_TUNE_WGRAD_ROWS = 2, SP_TUNE_DETERMINISTIC = 3,
+       SP_TUNE_SPLITK_TARGET = 4, SP_TUNE_SPLITK_MINSTEPS = 5, SP_TUNE_CONV1X1_DIRECT = 6, SP_TUNE_CONV_SHORT = 7,
+       SP_TUNE_WGRAD9_BLOCKS = 8, SP_TUNE_WGRAD_BLOCKS = 9, SP_TUNE_WGRAD_MINSTEPS = 10, SP_TUNE_WGRAD_SMALL_M = 11,
+       SP_TUNE_WGRAD_K1_TILE64 = 12, SP_TUNE_WGRAD_ROWS_THIN = 13, SP_TUNE_WGRAD_ROWS_BLOCKS = 14, SP_TUNE_WGRAD_ROWS_SLABS = 15,
+       SP_TUNE_COUNT = 16 };
 int sp_set_tuning(int32_t key, int32_t value);
 const char* sp_last_error_string(void);
 
@@ -140,7 +153,9 @@ int sp_linear_wgrad(const void* x, int32_t ldx, const void* dy, int32_t ld_dy, f
  * forward-pre-hook behind models.py:28,34,55,58,128,132,135,232-243,299-315,356-360,393-404,438-449):
  * one power iteration (in place on u, v) when power_iter != 0, sigma = u.(W v), then W/sigma is written
  * in the packings the conv / linear kernels read.  The table lives in DEVICE memory.
- *   scratch (fp32, per call): per layer at scratch_off: v-snapshot[cols], s[rows], u-snapshot[rows], {sigma, 1/sigma, -, -}
+ *   scratch (fp32, per call, needs no initialisation): per layer at scratch_off: v-snapshot[cols], s[rows], u-snapshot[rows],
+ *   {sigma, 1/sigma, -, -}; at part_off: ceil(rows/128) x cols floats (W^T u is formed as per-row-slab partial sums that are
+ *   added in a fixed order: the forward pass is bit-reproducible)
  *   pack_arena (per call): per layer fwd packing at fwd_off, dgrad packing at dgrad_off (byte offsets, -1 = none)
  *   max_pack_elems: >= the element count of the largest packing and >= 1024 * ceil(cin_p/32) * ceil(cout_p/32) of every
  *   layer (the packing kernel moves 32 x 32 x taps tiles; this bounds its 2-D grid).  taps <= 9.
@@ -153,6 +168,7 @@ typedef struct sp_sn_layer {
     float* u;              /* weight_u [rows]  (updated in place)                                  */
     float* v;              /* weight_v [cols]  (updated in place)                                  */
     int64_t scratch_off;   /* in floats                                                             */
+    int64_t part_off;      /* in floats: ceil(rows/128) x cols partial sums of W^T u (power iteration only; summed in order) */
     int64_t fwd_off;       /* bytes; layout [rows][taps][cin_p] dtype, or plain fp32 [rows][cols] if kind==1 */
     int64_t dgrad_off;     /* bytes; layout [cin][flipped taps][cout_p] dtype                       */
     int32_t rows, cols, cin, taps, cin_p, cout_p, kind, pack_block0;
@@ -167,7 +183,8 @@ int sp_sn_forward(const sp_sn_layer* table_dev, int32_t n_layers, int32_t max_ro
  * max_elems: largest rows*cols of the table.  accumulate_from (NULL, or a buffer laid out like `grads`, `grads` itself
  * included): the result is added to it - the gradients of a second forward through the same network (D(real) and D(fake),
  * model_wrapper.py:150-160) land on the first one's without one autograd addition per parameter.  bias_grads (NULL to
- * skip): the layers' bias-gradient slots of the arena are copied (accumulate_from == NULL) or added into it. */
+ * skip): the layers' bias-gradient slots of the arena are copied (accumulate_from == NULL) or added into it.
+ * dot_partials: n_layers x 512 floats of scratch (no initialisation): per-block partial sums of <dW, W>, added in block order. */
 typedef struct sp_sn_bwd_layer {
     const float* w;        /* weight_orig [rows][cols] */
     int64_t dw_off, dot_off, scratch_off, grad_off;
@@ -176,7 +193,7 @@ typedef struct sp_sn_bwd_layer {
 } sp_sn_bwd_layer;
 int sp_sn_backward_batched(const sp_sn_bwd_layer* table_dev, int32_t n_layers, int64_t max_elems, float* arena,
                            const float* scratch, float* grads, const float* accumulate_from, float* bias_grads,
-                           sp_stream_t stream);
+                           float* dot_partials, sp_stream_t stream);
 
 /* One-off packing of a frozen, non-normalised fp32 weight (the VGG-16 pyramid, models.py:176-181) into the
  * same two packings.  chw_c > 0: the input-feature index is permuted from NCHW-flatten (c*chw_hw + s) to
@@ -253,9 +270,11 @@ int sp_upsample2_bwd(const void* dy, void* dx, int32_t n, int32_t h, int32_t w_,
 /* ------------------------------------------------------------------------------------------------
  * SAGAN attention core (torch.bmm + softmax + torch.bmm at models.py:262-270): o = softmax(q k^T) v, no
  * 1/sqrt(d) scale.  q [b][n][d], k [b][nk][d], v [b][nk][dv], o [b][n][dv]; lse [b][n] fp32 saved for backward.
- * Backward: dk_f32 / dv_f32 are fp32 scratch of ceil(n / 64) slabs of [b][nk][d] resp. [b][nk][dv] floats (one partial
- * sum per 64-query block, reduced by the call; the fp32 path uses the first slab only); dk / dv receive the result.
+ * Backward: dk_f32 / dv_f32 are fp32 scratch of sp_attention_bwd_slabs() slabs of [b][nk][d] resp. [b][nk][dv] floats (one
+ * partial sum per query block - 64 queries on the bf16 MFMA path, 32 or 16 on the fp32 path - added in block order by the
+ * call: no atomics, no initialisation needed); dk / dv receive the result.
  * ---------------------------------------------------------------------------------------------- */
+int sp_attention_bwd_slabs(int32_t n, int32_t nk, int32_t d, int32_t dv, int32_t dtype, int64_t* slabs_out);
 int sp_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int32_t batch, int32_t n,
                      int32_t nk, int32_t d, int32_t dv, int32_t dtype, sp_stream_t stream);
 int sp_attention_bwd(const void* q, const void* k, const void* v, const void* dout, const float* lse, void* dq,
@@ -283,11 +302,13 @@ int sp_act_bwd(const void* dy, const void* y, void* dz, int64_t pixels, int32_t 
                int32_t dtype, sp_stream_t stream);
 int sp_scale_add(const void* a, const void* b, const float* g, void* y, int64_t numel, int32_t dtype,
                  sp_stream_t stream);
-int sp_scale_add_bwd(const void* dy, const void* a, const float* g, void* da, float* dg, int64_t numel,
+/* dg[0] = <dy, a>: per-block partial sums in `partials` (512 floats of scratch), added in block order by a second kernel */
+int sp_scale_add_bwd(const void* dy, const void* a, const float* g, void* da, float* dg, float* partials, int64_t numel,
                      int32_t dtype, sp_stream_t stream);
 int sp_permute_chw_hwc(const void* src, void* dst, int32_t batch, int32_t c, int32_t hw, int32_t to_hwc,
                        int32_t dtype, sp_stream_t stream);
-int sp_channel_sum(const void* x, int32_t ld, int64_t pixels, int32_t c, float* out, int32_t dtype,
+/* out[c] = sum over pixels; partials: 512 * c floats of scratch (per-block partial rows, added in block order) */
+int sp_channel_sum(const void* x, int32_t ld, int64_t pixels, int32_t c, float* out, float* partials, int32_t dtype,
                    sp_stream_t stream);
 int sp_f64_to_f32(const double* src, float* dst, int32_t n, sp_stream_t stream);
 
@@ -295,12 +316,14 @@ int sp_f64_to_f32(const double* src, float* dst, int32_t n, sp_stream_t stream);
  * Discriminator head (models.py:149-155; pred is the (B,B,F) tensor the reference produces) and the
  * losses (lossfunction.py:137,164 LSGAN; :31-68 semantic reconstruction, one call per pyramid level,
  * accumulating into acc; :92-110 diversity).  gout = device pointer to the upstream gradient scalar.
+ * sp_dhead_bwd: scratch = `batch` floats (per-sample sums handed from the first kernel to the second; no initialisation; the
+ * call keeps no state of its own, so it is re-entrant per stream); demb [num_classes][f] is zeroed by the call.
  * ---------------------------------------------------------------------------------------------- */
 int sp_dhead_fwd(const void* x, int32_t ldx, const float* emb_sn, const int64_t* cls, const float* wc,
                  const float* bc, float* pred, int32_t batch, int32_t f, int32_t dtype, sp_stream_t stream);
 int sp_dhead_bwd(const float* dpred, const void* x, int32_t ldx, const float* emb_sn, const int64_t* cls,
                  const float* wc, void* dx, int32_t lddx, float* demb, int32_t num_classes, float* dwc, float* dbc,
-                 int32_t batch, int32_t f, int32_t dtype, sp_stream_t stream);
+                 float* scratch, int32_t batch, int32_t f, int32_t dtype, sp_stream_t stream);
 int sp_sqerr_loss_fwd(const float* p, int64_t numel, float target, double* acc_tmp, float* loss, sp_stream_t stream);
 int sp_sqerr_loss_bwd(const float* p, int64_t numel, float target, const float* gout, float* dp, sp_stream_t stream);
 int sp_rec_loss_fwd(const void* real, int32_t ld_real, const void* fake, int32_t ld_fake, const float* mask,

@@ -173,23 +173,29 @@ def generator_forward(S: State, z: torch.Tensor, features: Sequence[torch.Tensor
 # --------------------------------------------------------------------------------------
 # discriminator (models.py:102-155, blocks :378-466)
 # --------------------------------------------------------------------------------------
-def discriminator_forward(S: State, x: torch.Tensor, class_id: torch.Tensor,
-                          training: bool = True) -> torch.Tensor:
-    """Returns the (B, B, 128) tensor the reference produces (models.py:151-155 quirk)."""
-    p = "layers.0"
+def discriminator_input_block(S: State, p: str, x: torch.Tensor, training: bool) -> torch.Tensor:
+    """DiscriminatorInputResidualBlock.forward (models.py:408-419)."""
     m = sn_conv(S, p + ".main_block.0", x, training, 1)
     m = sn_conv(S, p + ".main_block.2", lrelu(m), training, 1)
     r = sn_conv(S, p + ".residual_mapping", F.avg_pool2d(x, 2), training, 0)
-    x = F.avg_pool2d(m, 2) + r
+    return F.avg_pool2d(m, 2) + r
+
+
+def discriminator_residual_block(S: State, p: str, x: torch.Tensor, training: bool) -> torch.Tensor:
+    """DiscriminatorResidualBlock.forward (models.py:453-466)."""
+    m = sn_conv(S, p + ".main_block.1", lrelu(x), training, 1)
+    m = sn_conv(S, p + ".main_block.3", lrelu(m), training, 1)
+    r = sn_conv(S, p + ".residual_mapping", x, training, 0)
+    return F.avg_pool2d(m + r, 2)
+
+
+def discriminator_forward(S: State, x: torch.Tensor, class_id: torch.Tensor,
+                          training: bool = True) -> torch.Tensor:
+    """Returns the (B, B, 128) tensor the reference produces (models.py:151-155 quirk)."""
+    x = discriminator_input_block(S, "layers.0", x, training)
     for i in (1, 2, 3, 4, 5, 6, 7):
         p = "layers.%d" % i
-        if i == 3:
-            x = self_attention(S, p, x, training)
-            continue
-        m = sn_conv(S, p + ".main_block.1", lrelu(x), training, 1)
-        m = sn_conv(S, p + ".main_block.3", lrelu(m), training, 1)
-        r = sn_conv(S, p + ".residual_mapping", x, training, 0)
-        x = F.avg_pool2d(m + r, 2)
+        x = self_attention(S, p, x, training) if i == 3 else discriminator_residual_block(S, p, x, training)
     x = lrelu(x)
     x = F.adaptive_avg_pool2d(x, 1).flatten(1)
     x = lrelu(sn_linear(S, "layers.11", x, training))                       # (B, 128)

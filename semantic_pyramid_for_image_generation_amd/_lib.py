@@ -19,6 +19,13 @@ LIB_PATH = os.environ.get("SEMPYR_LIB") or os.path.join(_HERE, "libsempyr.so")  
 SP_F32, SP_BF16 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 
+# sp_set_tuning keys (include/sempyr.h).  The library reads no environment variables itself; an environment variable of
+# the same name (SP_CONV_TALL=0 ...) is forwarded ONCE, when the library is loaded - that is how A/B runs flip a switch.
+TUNE_KEYS = {"SP_CONV_TALL": 0, "SP_IGEMM_DMA": 1, "SP_WGRAD_ROWS": 2, "SP_DETERMINISTIC": 3, "SP_SPLITK_TARGET": 4,
+             "SP_SPLITK_MINSTEPS": 5, "SP_CONV1X1_DIRECT": 6, "SP_CONV_SHORT": 7, "SP_WGRAD9_BLOCKS": 8, "SP_WGRAD_BLOCKS": 9,
+             "SP_WGRAD_MINSTEPS": 10, "SP_WGRAD_SMALL_M": 11, "SP_WGRAD_K1_TILE64": 12, "SP_WGRAD_ROWS_THIN": 13,
+             "SP_WGRAD_ROWS_BLOCKS": 14, "SP_WGRAD_ROWS_SLABS": 15}
+
 
 class SpConvParams(ctypes.Structure):
     _fields_ = [("x", ctypes.c_void_p), ("w", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("y", ctypes.c_void_p),
@@ -32,7 +39,8 @@ class SpConvParams(ctypes.Structure):
 
 class SpSnLayer(ctypes.Structure):
     _fields_ = [("w", ctypes.c_void_p), ("u", ctypes.c_void_p), ("v", ctypes.c_void_p),
-                ("scratch_off", ctypes.c_int64), ("fwd_off", ctypes.c_int64), ("dgrad_off", ctypes.c_int64),
+                ("scratch_off", ctypes.c_int64), ("part_off", ctypes.c_int64), ("fwd_off", ctypes.c_int64),
+                ("dgrad_off", ctypes.c_int64),
                 ("rows", ctypes.c_int32), ("cols", ctypes.c_int32), ("cin", ctypes.c_int32), ("taps", ctypes.c_int32),
                 ("cin_p", ctypes.c_int32), ("cout_p", ctypes.c_int32), ("kind", ctypes.c_int32),
                 ("pack_block0", ctypes.c_int32)]
@@ -92,6 +100,9 @@ def lib():
             fn = getattr(handle, name)         # AttributeError if the symbol is not exported
             fn.restype = ret
             fn.argtypes = argtypes
+        for env_name, key in TUNE_KEYS.items():
+            if os.environ.get(env_name) not in (None, ""):
+                handle.sp_set_tuning(key, int(os.environ[env_name]))
         _lib = handle
     return _lib
 

@@ -14,8 +14,8 @@ extern "C" void sp_set_error(const char* fmt, ...) {
 extern "C" const char* sp_last_error_string(void) { return g_err; }
 extern "C" int sp_version(void) { return SP_VERSION; }
 
-// kernel-selection knobs for tests and A/B runs (-1 = default: environment variable, then built-in heuristic)
-int sp_g_tune[SP_TUNE_COUNT] = {-1, -1, -1};
+// knobs for tests and A/B runs (-1 = built-in default); the library itself never reads the environment
+int sp_g_tune[SP_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 extern "C" int sp_set_tuning(int32_t key, int32_t value) {
     if (key < 0 || key >= SP_TUNE_COUNT) { sp_set_error("sp_set_tuning: unknown key %d", key); return SP_ERR_INVALID; }
     sp_g_tune[key] = value;

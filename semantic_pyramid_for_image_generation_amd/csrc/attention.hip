@@ -4,7 +4,8 @@
 // One block = TQ queries of one image against all Nk keys: K (fp32, +1-padded rows) and the TQ x Nk score
 // tile live in LDS; V streams through L2.  0.2 GFLOP per image - VALU fp32 is ample here, the point of
 // the fusion is the 1 MB/image score round trip it removes.
-// Backward recomputes P from the saved log-sum-exp and accumulates dK / dV with fp32 atomics.
+// Backward recomputes P from the saved log-sum-exp; every query block stores its dK / dV contribution in its own fp32
+// slab and a reduce pass adds the slabs in block order (no atomics: bit-reproducible).
 #include "common.h"
 
 namespace {
@@ -560,11 +561,17 @@ int launch_attn_tq(bool fwd, const void* q, const void* k, const void* v, void* 
 }
 
 // 32 queries per block unless the backward's LDS tiles (keys + scores + dO + transposed V chunk) would not fit 160 KB
+inline int attn_valu_tq(int NK, int D, int DV) {
+    const long lds_b32 = (long)(NK * (D + 1) + 32 * D + 32 * DV + 32 * NK + 32 * 4 + 32 * (NK + 1)) * 4;
+    return lds_b32 <= 160 * 1024 ? 32 : 16;
+}
+inline bool attn_bwd_mfma_ok(int dtype, int nk, int d, int dv) {
+    return dtype == SP_BF16 && (d == 32 || d == 64) && dv % 32 == 0 && dv <= 256 && nk % 32 == 0;
+}
 template <typename T>
 int launch_attn(bool fwd, const void* q, const void* k, const void* v, void* o_or_dq, const void* dout, float* lse, float* dk,
                 float* dv, int B, int N, int NK, int D, int DV, hipStream_t s) {
-    const long lds_b32 = (long)(NK * (D + 1) + 32 * D + 32 * DV + 32 * NK + 32 * 4 + 32 * (NK + 1)) * 4;
-    if (lds_b32 <= 160 * 1024) return launch_attn_tq<T, 32>(fwd, q, k, v, o_or_dq, dout, lse, dk, dv, B, N, NK, D, DV, s);
+    if (attn_valu_tq(NK, D, DV) == 32) return launch_attn_tq<T, 32>(fwd, q, k, v, o_or_dq, dout, lse, dk, dv, B, N, NK, D, DV, s);
     return launch_attn_tq<T, 16>(fwd, q, k, v, o_or_dq, dout, lse, dk, dv, B, N, NK, D, DV, s);
 }
 
@@ -594,7 +601,7 @@ extern "C" int sp_attention_bwd(const void* q, const void* k, const void* v, con
     SP_CHECK_ARG(nk > 0 && nk <= 256 && d > 0 && d <= 64 && dv > 0 && dv <= 256, "sp_attention_bwd: unsupported extents nk=%d d=%d dv=%d", nk, d, dv);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const long nkd = (long)batch * nk * d, nkv = (long)batch * nk * dv;
-    if (dtype == SP_BF16 && (d == 32 || d == 64) && dv % 32 == 0 && dv <= 256 && nk % 32 == 0) {
+    if (attn_bwd_mfma_ok(dtype, nk, d, dv)) {
         const int nqb = sp_div_up(n, AB_QB);           // one partial slab per query block (scratch: nqb x the gradient size)
         const int lds = nk * (d * 2 + 32) + AB_QB * (d * 2 + 32) + AB_QB * (dv * 2 + 32) + 2 * AB_QB * (nk * 2 + 32);
         { static int done4 = 0; if (done4 < lds) { hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds); done4 = lds; } }
@@ -605,19 +612,25 @@ extern "C" int sp_attention_bwd(const void* q, const void* k, const void* v, con
         SP_LAUNCH_CHECK();
         return SP_OK;
     }
-    hipError_t e = hipMemsetAsync(dk_f32, 0, sizeof(float) * (size_t)batch * nk * d, s);
-    if (e == hipSuccess) e = hipMemsetAsync(dv_f32, 0, sizeof(float) * (size_t)batch * nk * dv, s);
-    if (e != hipSuccess) { sp_set_error("sp_attention_bwd: memset failed"); return SP_ERR_LAUNCH; }
+    // VALU path (fp32 storage, odd extents): one slab per block of TQ queries, summed in block order
+    SP_CHECK_ARG(nkd % 4 == 0 && nkv % 4 == 0, "sp_attention_bwd: batch*nk*d and batch*nk*dv must be multiples of 4");
+    const int nqb = sp_div_up(n, attn_valu_tq(nk, d, dv));
     int rc = dtype == SP_F32 ? launch_attn<float>(false, q, k, v, dq, dout, const_cast<float*>(lse), dk_f32, dv_f32, batch, n, nk, d, dv, s)
                              : launch_attn<bf16>(false, q, k, v, dq, dout, const_cast<float*>(lse), dk_f32, dv_f32, batch, n, nk, d, dv, s);
     if (rc != SP_OK) return rc;
     if (dtype == SP_F32) {
-        hipLaunchKernelGGL(cast_f32_kernel<float>, dim3(sp_div_up(nkd, 256)), dim3(256), 0, s, dk_f32, (float*)dk, nkd);
-        hipLaunchKernelGGL(cast_f32_kernel<float>, dim3(sp_div_up(nkv, 256)), dim3(256), 0, s, dv_f32, (float*)dv_out, nkv);
+        hipLaunchKernelGGL(attn_reduce_kernel<float>, dim3(sp_div_up(nkd / 4, 256)), dim3(256), 0, s, dk_f32, nqb, nkd, (float*)dk);
+        hipLaunchKernelGGL(attn_reduce_kernel<float>, dim3(sp_div_up(nkv / 4, 256)), dim3(256), 0, s, dv_f32, nqb, nkv, (float*)dv_out);
     } else {
-        hipLaunchKernelGGL(cast_f32_kernel<bf16>, dim3(sp_div_up(nkd, 256)), dim3(256), 0, s, dk_f32, (bf16*)dk, nkd);
-        hipLaunchKernelGGL(cast_f32_kernel<bf16>, dim3(sp_div_up(nkv, 256)), dim3(256), 0, s, dv_f32, (bf16*)dv_out, nkv);
+        hipLaunchKernelGGL(attn_reduce_kernel<bf16>, dim3(sp_div_up(nkd / 4, 256)), dim3(256), 0, s, dk_f32, nqb, nkd, (bf16*)dk);
+        hipLaunchKernelGGL(attn_reduce_kernel<bf16>, dim3(sp_div_up(nkv / 4, 256)), dim3(256), 0, s, dv_f32, nqb, nkv, (bf16*)dv_out);
     }
     SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_attention_bwd_slabs(int32_t n, int32_t nk, int32_t d, int32_t dv, int32_t dtype, int64_t* slabs_out) {
+    SP_CHECK_ARG(slabs_out && n > 0 && nk > 0 && d > 0 && dv > 0, "sp_attention_bwd_slabs: bad args");
+    *slabs_out = attn_bwd_mfma_ok(dtype, nk, d, dv) ? sp_div_up(n, AB_QB) : sp_div_up(n, attn_valu_tq(nk, d, dv));
     return SP_OK;
 }

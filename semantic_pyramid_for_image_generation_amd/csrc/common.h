@@ -134,8 +134,11 @@ template <> struct VecIO<bf16, 8> {
     }
 };
 
-// kernel-selection knobs (sp_set_tuning, api.cpp); -1 = default
+// knobs (sp_set_tuning, api.cpp); -1 = default
 extern int sp_g_tune[SP_TUNE_COUNT];
+static inline int sp_tune(int key, int dflt) { return sp_g_tune[key] >= 0 ? sp_g_tune[key] : dflt; }
+// fixed-order reductions (no fp32 atomics): always in the fp32 parity mode, on request in the bf16 throughput mode
+static inline bool sp_deterministic(int dtype) { return sp_g_tune[SP_TUNE_DETERMINISTIC] >= 0 ? sp_g_tune[SP_TUNE_DETERMINISTIC] != 0 : dtype == SP_F32; }
 // conv_wgrad_rows.hip: SP_OK after launching, 1 if the shape is not covered
 int sp_wgrad_rows_launch(const void* x, const void* dy, float* dw, float* dbias, int n, int h, int w, int cin, int cout,
                          int ld_dy, float* ws, long ws_floats, int dy_up2, hipStream_t s);

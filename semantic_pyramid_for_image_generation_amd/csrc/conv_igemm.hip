@@ -1135,8 +1135,9 @@ int launch_tall(const sp_conv_params& p, hipStream_t s) {
 
 // number of K splits for `tiles` output tiles and nk K-steps: aim at ~2.5 blocks per CU, at least 6 K-steps per split
 inline int split_k_plan(int tiles, int nk) {
-    static const int target = getenv("SP_SPLITK_TARGET") ? atoi(getenv("SP_SPLITK_TARGET")) : 640;
-    static const int min_steps = getenv("SP_SPLITK_MINSTEPS") ? atoi(getenv("SP_SPLITK_MINSTEPS")) : 6;
+    const int target = sp_tune(SP_TUNE_SPLITK_TARGET, 640);
+    int min_steps = sp_tune(SP_TUNE_SPLITK_MINSTEPS, 6);
+    if (min_steps < 1) min_steps = 1;
     if (tiles > 256 || nk < 16) return 1;           // more tiles than CUs: a split only adds the finalize pass (measured)
     int ksplit = (target + tiles - 1) / tiles;
     if (ksplit > nk / min_steps) ksplit = nk / min_steps;
@@ -1301,23 +1302,19 @@ int launch_1x1_direct(const sp_conv_params& p, hipStream_t s) {
     return SP_OK;
 }
 
-// kernel-selection knobs: sp_set_tuning() (tests, A/B runs) overrides the environment
-int env_tall_mode() { static const int m = getenv("SP_CONV_TALL") ? atoi(getenv("SP_CONV_TALL")) : 1; return m; }
-int env_dma_mode() { static const int m = getenv("SP_IGEMM_DMA") ? atoi(getenv("SP_IGEMM_DMA")) : 1; return m; }
 
 template <typename T>
 int dispatch(const sp_conv_params& p, hipStream_t s) {
     const long M = (long)p.n * p.h * p.w_;
     if (sizeof(T) == 2 && p.ksize == 1 && p.cin_p <= 1024) {
-        static const int direct = getenv("SP_CONV1X1_DIRECT") ? atoi(getenv("SP_CONV1X1_DIRECT")) : 1;
-        if (direct) return launch_1x1_direct(p, s);
+        if (sp_tune(SP_TUNE_CONV1X1_DIRECT, 1)) return launch_1x1_direct(p, s);
     }
     // cout <= 16 on a big feature map (the generator's RGB head, 64 -> 3 @256^2): memory-bound; the halo-reuse kernels read
     // the input once instead of once per tap, which outweighs the idle MFMA rows (158 -> ~85 us)
     const bool thin_big = p.cout <= 16 && p.cin_p >= 32 && M >= (1L << 18);
     if (p.ksize == 3 && (p.cout > 32 || thin_big) && p.h % HALO_TH == 0 && p.w_ % HALO_TW == 0) {
         // persistent tall kernel (half the LDS reads per MFMA, LDS-DMA pipeline across tiles); SP_CONV_TALL=0 disables, 2 forces
-        const int tall_mode = sp_g_tune[SP_TUNE_CONV_TALL] >= 0 ? sp_g_tune[SP_TUNE_CONV_TALL] : env_tall_mode();
+        const int tall_mode = sp_tune(SP_TUNE_CONV_TALL, 1);
         const long esz = p.dtype == SP_F32 ? 4 : 2;
         const bool fits30 = (long)p.n * p.h * p.w_ * p.cin_p * esz < (1L << 30) && (long)p.cout * 9 * p.cin_p * esz < (1L << 30);
         const bool tall_ok = tall_mode && fits30 && p.h % TL_TH == 0 && p.w_ % TL_TW == 0;
@@ -1335,13 +1332,13 @@ int dispatch(const sp_conv_params& p, hipStream_t s) {
         }
         // remaining Cout > 64 layers: the 128 co x 8x32 tile on the LDS-DMA pipeline of the tall kernel (TH = 8; measured 74 ->
         // 67 us per launch in the step, 902 -> 914 img/s) or, with SP_CONV_SHORT=0 / tall_mode 0, on the register-staged halo kernel
-        static const int short_env = getenv("SP_CONV_SHORT") ? atoi(getenv("SP_CONV_SHORT")) : 1;
+        const int short_env = sp_tune(SP_TUNE_CONV_SHORT, 1);
         if (fits30 && (tall_mode == 3 || (tall_mode == 1 && short_env))) return launch_tall<T, 2, 8>(p, s);
         return launch_halo<T, 128, 3>(p, s);
     }
     // LDS-DMA kernel: measured faster for the small-spatial 3x3 layers (latency-bound), slower for 1x1 (profiles/README.md);
     // SP_IGEMM_DMA=2 forces it everywhere, 0 disables it
-    const int dma_mode = sp_g_tune[SP_TUNE_IGEMM_DMA] >= 0 ? sp_g_tune[SP_TUNE_IGEMM_DMA] : env_dma_mode();
+    const int dma_mode = sp_tune(SP_TUNE_IGEMM_DMA, 1);
     const long esz_ = p.dtype == SP_F32 ? 4 : 2;
     const bool dma_fits = M * p.cin_p * esz_ < (1L << 30) && (long)p.cout * p.ksize * p.ksize * p.cin_p * esz_ < (1L << 30);
     if (p.cout > 16 && dma_fits && (dma_mode == 2 || (dma_mode == 1 && p.ksize == 3 && M <= 8192))) {
@@ -1365,7 +1362,7 @@ extern "C" int sp_conv2d_workspace(int32_t n, int32_t h, int32_t w_, int32_t cin
     *bytes_out = 0;
     // mirrors dispatch(): only the LDS-DMA implicit GEMM (3x3, small spatial extent) splits K
     const long M = (long)n * h * w_;
-    const int dma_mode = sp_g_tune[SP_TUNE_IGEMM_DMA] >= 0 ? sp_g_tune[SP_TUNE_IGEMM_DMA] : env_dma_mode();
+    const int dma_mode = sp_tune(SP_TUNE_IGEMM_DMA, 1);
     const bool halo_path = ksize == 3 && cout > 32 && h % HALO_TH == 0 && w_ % HALO_TW == 0;
     if (ksize != 3 || halo_path || cout <= 16 || M > 8192 || dma_mode == 0) return SP_OK;
     const int co_t = cout <= 32 ? 32 : 64, px_t = cout <= 64 ? 256 : 64;

@@ -10,8 +10,9 @@
 //         same permutation of the reduction index for A and B, so each 32-lane half touches 8
 //         consecutive LDS rows; with a row pitch of (tile bytes + 32) they fall on distinct banks.
 //   fp32: v_mfma_f32_16x16x4_f32 takes one k per lane: plain ds_read_b32 down a column. Exact fp32.
-// Split-K over pixel ranges (grid.z = taps * nsplit) with fp32 atomic accumulation into dW, which is
-// zeroed by the call.
+// Split-K over pixel ranges (grid.z = taps * nsplit).  The splits meet either through fp32 atomics on dW (throughput mode) or,
+// in the deterministic mode (SP_TUNE_DETERMINISTIC; default for fp32 storage), through one partial slab per split that an
+// ordered reduce pass sums (fp64) and adds to dW: bit-identical results run to run.
 #include <cstdlib>
 #include "common.h"
 
@@ -27,7 +28,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ x
                                                          int COUT, int LD_DY, int ksize, int nsplit,
                                                          long px_per_split, float* __restrict__ dbias,
                                                          const T* __restrict__ w_packed, float* __restrict__ dot,
-                                                         float* __restrict__ slabs, long n_dw) {
+                                                         float* __restrict__ slabs, long n_dw, float* __restrict__ bias_slabs,
+                                                         int bias_ld) {
     constexpr int CO_T = 2 * FCO * 16, CI_T = 2 * FCI * 16;
     constexpr int E = 16 / (int)sizeof(T);
     constexpr int PK = WgTraits<T>::PK;
@@ -284,7 +286,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ x
             const int col = tid / E, e = tid - col * E;
             float t = 0.f;
             for (int rr = 0; rr < 256 / A_CPR; ++rr) t += red[(rr * A_CPR + col) * E + e];
-            if (co0 + tid < COUT) atomicAdd(dbias + co0 + tid, t);
+            if (co0 + tid < COUT) {
+                if (bias_slabs != nullptr) bias_slabs[(long)split * bias_ld + co0 + tid] = t;   // one writer per (split, co)
+                else atomicAdd(dbias + co0 + tid, t);
+            }
         }
     }
 }
@@ -307,7 +312,8 @@ template <typename T>
 __global__ __launch_bounds__(256, 2) void conv_wgrad9_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw,
                                                           int N, int H, int W, int CIN, int COUT, int LD_DY, int segs_per_split,
                                                           float* __restrict__ dbias, const T* __restrict__ w_packed,
-                                                          float* __restrict__ dot, float* __restrict__ slabs, long n_dw) {
+                                                          float* __restrict__ dot, float* __restrict__ slabs, long n_dw,
+                                                          float* __restrict__ bias_slabs, int bias_ld) {
     constexpr int E = 16 / (int)sizeof(T);
     constexpr int PXS = Wg9Traits<T>::PXS, PITCH = Wg9Traits<T>::PITCH;
     constexpr int CPR = 64 / E;                           // 16-byte chunks per 64-channel row
@@ -504,25 +510,34 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad9_kernel(const T* __restrict
             const int col = tid / E, e = tid - col * E;
             float t = 0.f;
             for (int rr = 0; rr < 256 / CPR; ++rr) t += red[(rr * CPR + col) * E + e];
-            if (co0 + tid < COUT) atomicAdd(dbias + co0 + tid, t);
+            if (co0 + tid < COUT) {
+                if (bias_slabs != nullptr) bias_slabs[(long)blockIdx.z * bias_ld + co0 + tid] = t;
+                else atomicAdd(dbias + co0 + tid, t);
+            }
         }
     }
 }
 
 
-// Sums the per-split partial tiles (slab mode) into dW and forms <dW, W/sigma> in the same pass.
+// Adds the per-split partial tiles (slab mode), summed in split order in fp64, to dW (and the per-split bias sums to dbias);
+// forms <dW, W/sigma> of the legacy fused entry in the same pass.
 template <typename T>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int nsplit, long n_dw, float* __restrict__ dw,
-                                                           const T* __restrict__ w_packed, float* __restrict__ dot) {
+                                                           const T* __restrict__ w_packed, float* __restrict__ dot,
+                                                           const float* __restrict__ bias_slabs, int bias_ld, int cout,
+                                                           float* __restrict__ dbias) {
     __shared__ float red[4];
     float dpart = 0.f;
     for (long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4; e < n_dw; e += (long)gridDim.x * 1024) {
-        float4 a = *reinterpret_cast<const float4*>(slabs + e);
-        for (int sidx = 1; sidx < nsplit; ++sidx) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        for (int sidx = 0; sidx < nsplit; ++sidx) {
             const float4 b = *reinterpret_cast<const float4*>(slabs + (long)sidx * n_dw + e);
-            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            a0 += b.x; a1 += b.y; a2 += b.z; a3 += b.w;
         }
-        *reinterpret_cast<float4*>(dw + e) = a;
+        float4 d = *reinterpret_cast<const float4*>(dw + e);
+        const float4 a = make_float4((float)a0, (float)a1, (float)a2, (float)a3);
+        d.x += a.x; d.y += a.y; d.z += a.z; d.w += a.w;
+        *reinterpret_cast<float4*>(dw + e) = d;
         if (w_packed != nullptr) {
             float wv[4];
             Elem<T>::ld4(w_packed + e, wv);
@@ -532,6 +547,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (w_packed != nullptr) {
         const float tot = block_sum_256(dpart, red);
         if (threadIdx.x == 0) atomicAdd(dot, tot);
+    }
+    if (bias_slabs != nullptr && blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < cout; c += 256) {
+            double t = 0.0;
+            for (int sidx = 0; sidx < nsplit; ++sidx) t += bias_slabs[(long)sidx * bias_ld + c];
+            dbias[c] += (float)t;
+        }
     }
 }
 
@@ -545,7 +567,7 @@ WgPlan plan_wgrad(int n, int h, int w, int cin, int cout, int ksize, int co_t, i
     if (pl.nine) {
         const long nseg = (long)n * h * (w / Wg9Traits<T>::PXS);
         const int tiles = sp_div_up(cin, 64) * sp_div_up(cout, 64);
-        static const int target9 = getenv("SP_WGRAD9_BLOCKS") ? atoi(getenv("SP_WGRAD9_BLOCKS")) : 512;
+        const int target9 = sp_tune(SP_TUNE_WGRAD9_BLOCKS, 512);
         long nsplit = (target9 + tiles - 1) / tiles;
         if (nsplit > nseg / 8) nsplit = nseg / 8;
         if (nsplit < 1) nsplit = 1;
@@ -558,11 +580,12 @@ WgPlan plan_wgrad(int n, int h, int w, int cin, int cout, int ksize, int co_t, i
         const int tiles = sp_div_up(cin, ci_t) * sp_div_up(cout, co_t) * taps;
         const long steps = (M + PK - 1) / PK;
         // split-K trades parallelism against reduction traffic: measured optimum ~1024 blocks for large images, ~256 for
-        // <= 8192 pixels (profiles/README.md); SP_WGRAD_BLOCKS overrides
-        static const int env_blocks = getenv("SP_WGRAD_BLOCKS") ? atoi(getenv("SP_WGRAD_BLOCKS")) : 0;
+        // <= 8192 pixels (profiles/README.md); SP_TUNE_WGRAD_BLOCKS overrides
+        const int env_blocks = sp_tune(SP_TUNE_WGRAD_BLOCKS, 0);
         const int target_blocks = env_blocks > 0 ? env_blocks : (M <= 8192 ? 256 : 1024);
         int nsplit = (target_blocks + tiles - 1) / tiles;
-        static const int min_steps = getenv("SP_WGRAD_MINSTEPS") ? atoi(getenv("SP_WGRAD_MINSTEPS")) : 4;
+        int min_steps = sp_tune(SP_TUNE_WGRAD_MINSTEPS, 4);
+        if (min_steps < 1) min_steps = 1;
         if (nsplit > steps / min_steps) nsplit = (int)(steps / min_steps);
         if (nsplit < 1) nsplit = 1;
         const long pps = ((steps + nsplit - 1) / nsplit) * PK;
@@ -579,7 +602,7 @@ inline void wgrad_tile(int cin, int cout, int& co_t, int& ci_t) {
 
 template <typename T>
 int launch_wgrad9(const T* x, const T* dy, float* dw, int n, int h, int w, int cin, int cout, int ld_dy, float* dbias,
-                  const T* w_packed, float* dot, float* slabs, const WgPlan& pl, hipStream_t s) {
+                  const T* w_packed, float* dot, float* slabs, float* bias_slabs, int bias_ld, const WgPlan& pl, hipStream_t s) {
     constexpr int PXS = Wg9Traits<T>::PXS, PITCH = Wg9Traits<T>::PITCH;
     constexpr int LDS = (PXS + 3 * (PXS + 2)) * PITCH;
     static bool attr_set = false;
@@ -591,14 +614,16 @@ int launch_wgrad9(const T* x, const T* dy, float* dw, int n, int h, int w, int c
     }
     const long n_dw = (long)cout * 9 * cin;
     dim3 grid(sp_div_up(cin, 64), sp_div_up(cout, 64), (unsigned)pl.nsplit);
-    hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, x, dy, dw, n, h, w, cin, cout, ld_dy, (int)pl.per_split, dbias, w_packed, dot, slabs, n_dw);
+    hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, x, dy, dw, n, h, w, cin, cout, ld_dy, (int)pl.per_split, dbias, w_packed, dot, slabs, n_dw,
+                       bias_slabs, bias_ld);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }
 
 template <typename T, int FCO, int FCI>
 int launch_wgrad(const T* x, const T* dy, float* dw, int n, int h, int w, int cin, int cout, int ld_dy, int ksize,
-                 float* dbias, const T* w_packed, float* dot, float* slabs, const WgPlan& pl, hipStream_t s) {
+                 float* dbias, const T* w_packed, float* dot, float* slabs, float* bias_slabs, int bias_ld, const WgPlan& pl,
+                 hipStream_t s) {
     constexpr int CO_T = 2 * FCO * 16, CI_T = 2 * FCI * 16, PK = WgTraits<T>::PK;
     constexpr int LDS = 2 * PK * ((CO_T + CI_T) * (int)sizeof(T) + 2 * WgTraits<T>::PAD);
     static bool attr_set = false;
@@ -612,9 +637,31 @@ int launch_wgrad(const T* x, const T* dy, float* dw, int n, int h, int w, int ci
     const long n_dw = (long)cout * taps * cin;
     dim3 grid(sp_div_up(cin, CI_T), sp_div_up(cout, CO_T), taps * pl.nsplit);
     hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, x, dy, dw, n, h, w, cin, cout, ld_dy, ksize, pl.nsplit, pl.per_split, dbias, w_packed, dot,
-                       slabs, n_dw);
+                       slabs, n_dw, bias_slabs, bias_ld);
     SP_LAUNCH_CHECK();
     return SP_OK;
+}
+
+// tile shape + split plan of the per-tap kernels for one layer (shared by the dispatcher and the workspace query)
+template <typename T>
+WgPlan pertap_plan(int n, int h, int w, int cin, int cout, int ksize, int& co_t, int& ci_t) {
+    wgrad_tile(cin, cout, co_t, ci_t);
+    // tiny pixel counts (8x8, 4x4 maps): the operands live in L2, so 64 x 64 tiles cost nothing extra and give enough blocks
+    // without a K split - no merge at all (SP_TUNE_WGRAD_SMALL_M, default 2048 pixels)
+    const long small_m = sp_tune(SP_TUNE_WGRAD_SMALL_M, 2048);
+    // 1x1 layers: dW is at most 256 x 256, so 64 x 64 tiles quadruple the tile count and shorten every merge
+    const int k1_small = sp_tune(SP_TUNE_WGRAD_K1_TILE64, 1);
+    if ((long)n * h * w <= small_m || (ksize == 1 && k1_small)) co_t = ci_t = 64;
+    return plan_wgrad<T>(n, h, w, cin, cout, ksize, co_t, ci_t);
+}
+
+// fp32 scratch (floats) the deterministic merge of this layer needs: one dW slab + one bias row per split
+template <typename T>
+long pertap_slab_floats(int n, int h, int w, int cin, int cout, int ksize) {
+    int co_t, ci_t;
+    const WgPlan pl = pertap_plan<T>(n, h, w, cin, cout, ksize, co_t, ci_t);
+    if (pl.nsplit <= 1) return 0;
+    return (long)pl.nsplit * ((long)cout * ksize * ksize * cin + ((cout + 3) & ~3));
 }
 
 template <typename T>
@@ -623,41 +670,40 @@ int dispatch_wgrad(const void* x, const void* dy, float* dw, int n, int h, int w
     const T* xt = reinterpret_cast<const T*>(x);
     const T* dt = reinterpret_cast<const T*>(dy);
     const T* wpk = reinterpret_cast<const T*>(w_packed);
+    const bool det = sp_deterministic(sizeof(T) == 2 ? SP_BF16 : SP_F32);
     if (sizeof(T) == 2 && ksize == 3 && w_packed == nullptr && dot == nullptr) {
         // row-walker kernel (conv_wgrad_rows.hip): all nine taps per block, 4.4x fewer L2 bytes per flop
-        static const int env_mode = getenv("SP_WGRAD_ROWS") ? atoi(getenv("SP_WGRAD_ROWS")) : 1;
-        const int mode = sp_g_tune[SP_TUNE_WGRAD_ROWS] >= 0 ? sp_g_tune[SP_TUNE_WGRAD_ROWS] : env_mode;
-        if (mode) {
+        if (sp_tune(SP_TUNE_WGRAD_ROWS, 1)) {
             const int rc = sp_wgrad_rows_launch(x, dy, dw, dbias, n, h, w, cin, cout, ld_dy, ws, ws_floats, 0, s);
             if (rc != 1) return rc;
         }
     }
-    // the per-tap kernels keep their atomics (their slab mode measured slower); the workspace is the row walker's only
-    ws = nullptr;
-    ws_floats = 0;
+    // throughput mode: the per-tap kernels keep their atomics (their slab mode measured slower); deterministic mode: slabs
+    if (!det) { ws = nullptr; ws_floats = 0; }
     int co_t, ci_t;
-    wgrad_tile(cin, cout, co_t, ci_t);
-    // tiny pixel counts (8x8, 4x4 maps): the operands live in L2, so 64 x 64 tiles cost nothing extra and give enough blocks
-    // without a K split - no atomic merge (SP_WGRAD_SMALL_M, default 2048 pixels)
-    static const long small_m = getenv("SP_WGRAD_SMALL_M") ? atol(getenv("SP_WGRAD_SMALL_M")) : 2048;
-    // 1x1 layers: dW is at most 256 x 256, so 64 x 64 tiles quadruple the tile count and shorten every atomic merge
-    static const int k1_small = getenv("SP_WGRAD_K1_TILE64") ? atoi(getenv("SP_WGRAD_K1_TILE64")) : 1;
-    if ((long)n * h * w <= small_m || (ksize == 1 && k1_small)) co_t = ci_t = 64;
-    const WgPlan pl = plan_wgrad<T>(n, h, w, cin, cout, ksize, co_t, ci_t);
+    const WgPlan pl = pertap_plan<T>(n, h, w, cin, cout, ksize, co_t, ci_t);
     const long n_dw = (long)cout * ksize * ksize * cin;
-    // slab mode: every split stores its partial tile with plain stores and a second pass sums them (and forms the
-    // spectral-norm inner product); without a workspace the splits meet through fp32 atomics
-    float* slabs = (ws != nullptr && pl.nsplit > 1 && ws_floats >= (long)pl.nsplit * n_dw && (n_dw & 3) == 0) ? ws : nullptr;
+    const int bias_ld = (cout + 3) & ~3;
+    // slab mode: every split stores its partial tile (and bias row) with plain stores and a second pass sums them in split
+    // order; without it the splits meet through fp32 atomics.  A single split owns its dW rows: no merge either way.
+    float* slabs = (ws != nullptr && pl.nsplit > 1 && ws_floats >= (long)pl.nsplit * (n_dw + bias_ld) && (n_dw & 3) == 0) ? ws : nullptr;
+    if (det && pl.nsplit > 1 && slabs == nullptr) {
+        sp_set_error("weight gradient: the deterministic mode needs the %ld floats of scratch sp_conv2d_wgrad_workspace() reports (got %ld)",
+                     (long)pl.nsplit * (n_dw + bias_ld), ws_floats);
+        return SP_ERR_INVALID;
+    }
+    float* bias_slabs = (slabs != nullptr && dbias != nullptr) ? slabs + (long)pl.nsplit * n_dw : nullptr;
     int rc;
-    if (pl.nine) rc = launch_wgrad9<T>(xt, dt, dw, n, h, w, cin, cout, ld_dy, dbias, wpk, dot, slabs, pl, s);
-    else if (co_t == 64 && ci_t == 64) rc = launch_wgrad<T, 2, 2>(xt, dt, dw, n, h, w, cin, cout, ld_dy, ksize, dbias, wpk, dot, slabs, pl, s);
-    else if (co_t == 64) rc = launch_wgrad<T, 2, 4>(xt, dt, dw, n, h, w, cin, cout, ld_dy, ksize, dbias, wpk, dot, slabs, pl, s);
-    else if (ci_t == 64) rc = launch_wgrad<T, 4, 2>(xt, dt, dw, n, h, w, cin, cout, ld_dy, ksize, dbias, wpk, dot, slabs, pl, s);
-    else rc = launch_wgrad<T, 4, 4>(xt, dt, dw, n, h, w, cin, cout, ld_dy, ksize, dbias, wpk, dot, slabs, pl, s);
+    if (pl.nine) rc = launch_wgrad9<T>(xt, dt, dw, n, h, w, cin, cout, ld_dy, dbias, wpk, dot, slabs, bias_slabs, bias_ld, pl, s);
+    else if (co_t == 64 && ci_t == 64) rc = launch_wgrad<T, 2, 2>(xt, dt, dw, n, h, w, cin, cout, ld_dy, ksize, dbias, wpk, dot, slabs, bias_slabs, bias_ld, pl, s);
+    else if (co_t == 64) rc = launch_wgrad<T, 2, 4>(xt, dt, dw, n, h, w, cin, cout, ld_dy, ksize, dbias, wpk, dot, slabs, bias_slabs, bias_ld, pl, s);
+    else if (ci_t == 64) rc = launch_wgrad<T, 4, 2>(xt, dt, dw, n, h, w, cin, cout, ld_dy, ksize, dbias, wpk, dot, slabs, bias_slabs, bias_ld, pl, s);
+    else rc = launch_wgrad<T, 4, 4>(xt, dt, dw, n, h, w, cin, cout, ld_dy, ksize, dbias, wpk, dot, slabs, bias_slabs, bias_ld, pl, s);
     if (rc != SP_OK || slabs == nullptr) return rc;
     long blocks = (n_dw / 4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(wgrad_reduce_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, slabs, pl.nsplit, n_dw, dw, wpk, dot);
+    hipLaunchKernelGGL(wgrad_reduce_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, slabs, pl.nsplit, n_dw, dw, wpk, dot, bias_slabs, bias_ld,
+                       cout, dbias);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }
@@ -667,8 +713,14 @@ int dispatch_wgrad(const void* x, const void* dy, float* dw, int n, int h, int w
 extern "C" int sp_conv2d_wgrad_workspace(int32_t n, int32_t h, int32_t w_, int32_t cin_p, int32_t cout, int32_t ksize,
                                          int32_t dtype, int64_t* floats_out) {
     SP_CHECK_ARG(floats_out && n > 0 && h > 0 && w_ > 0 && cin_p > 0 && cout > 0 && (ksize == 1 || ksize == 3), "sp_conv2d_wgrad_workspace: bad args");
-    // scratch the row-walker kernel wants for its per-block partial tiles (bf16, 3x3, W % 32 == 0); 0 otherwise
-    *floats_out = (dtype == SP_BF16 && ksize == 3) ? (int64_t)sp_wgrad_rows_workspace(n, h, w_, cin_p, cout) : 0;
+    // scratch the row-walker kernel wants for its per-block partial tiles (bf16, 3x3, W % 32 == 0) ...
+    int64_t need = (dtype == SP_BF16 && ksize == 3 && sp_tune(SP_TUNE_WGRAD_ROWS, 1)) ? (int64_t)sp_wgrad_rows_workspace(n, h, w_, cin_p, cout) : 0;
+    // ... and, in the deterministic mode, the per-split slabs of the per-tap kernels for every other shape
+    if (sp_deterministic(dtype)) {
+        const int64_t slab = dtype == SP_F32 ? pertap_slab_floats<float>(n, h, w_, cin_p, cout, ksize) : pertap_slab_floats<bf16>(n, h, w_, cin_p, cout, ksize);
+        if (slab > need) need = slab;
+    }
+    *floats_out = need;
     return SP_OK;
 }
 

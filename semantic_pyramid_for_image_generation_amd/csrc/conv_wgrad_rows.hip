@@ -331,19 +331,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_rows_kernel(WrArgs a) {
 // dW through atomics.
 __global__ __launch_bounds__(256) void conv_wgrad_rows_reduce_kernel(const float* __restrict__ slabs, int nblk, float* __restrict__ dw,
                                                                      int CIN, int COUT, int ci_tiles, const float* __restrict__ bias_part,
-                                                                     float* __restrict__ dbias) {
+                                                                     float* __restrict__ dbias, int ordered) {
     const int co0 = (blockIdx.y / ci_tiles) * 64, ci0 = (blockIdx.y % ci_tiles) * 64;
-    if (bias_part != nullptr && blockIdx.z == 0 && ci0 == 0) {
+    if (bias_part != nullptr && blockIdx.z == 0 && ci0 == 0 && (!ordered || blockIdx.x == 0)) {
         // bias gradient: the per-block partial sums of this co tile, split over the gridDim.x blocks of the pair and the four
         // 64-thread groups of a block (a single chain over 512 partials took longer than the whole tile reduction)
         __shared__ float bred[256];
         const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
         const float* bp = bias_part + (long)(blockIdx.y / ci_tiles) * nblk * 64 + col;
         float t = 0.f;
-        for (int k = blockIdx.x * 4 + grp; k < nblk; k += gridDim.x * 4) t += bp[(long)k * 64];
+        // ordered: block 0 of the pair alone sums all partials (fixed order) and is the only writer of its dbias entries
+        const int kstep = ordered ? 4 : gridDim.x * 4;
+        for (int k = (ordered ? 0 : blockIdx.x * 4) + grp; k < nblk; k += kstep) t += bp[(long)k * 64];
         bred[threadIdx.x] = t;
         __syncthreads();
-        if (threadIdx.x < 64 && co0 + col < COUT) atomicAdd(dbias + co0 + col, bred[col] + bred[64 + col] + bred[128 + col] + bred[192 + col]);
+        if (threadIdx.x < 64 && co0 + col < COUT) {
+            const float tot = bred[col] + bred[64 + col] + bred[128 + col] + bred[192 + col];
+            if (ordered) dbias[co0 + col] += tot; else atomicAdd(dbias + co0 + col, tot);
+        }
     }
     const float* base = slabs + (long)blockIdx.y * nblk * (9 * 64 * 64);
     const int e4 = blockIdx.x * 256 + threadIdx.x;                 // float4 index inside the tile: [tap][co][ci / 4]
@@ -384,16 +389,16 @@ int sp_wgrad_rows_launch(const void* x, const void* dy, float* dw, float* dbias,
     a.dbias = dbias;
     a.N = n; a.H = h; a.W = w; a.CIN = cin; a.COUT = cout; a.LD_DY = ld_dy;
     a.dy_up2 = dy_up2;
-    static const int env_thin = getenv("SP_WGRAD_ROWS_THIN") ? atoi(getenv("SP_WGRAD_ROWS_THIN")) : 1;
-    a.thin_mode = env_thin;
+    a.thin_mode = sp_tune(SP_TUNE_WGRAD_ROWS_THIN, 1);
     const int co_tiles = (cout + 63) / 64;
     a.ci_tiles = (cin + 63) / 64;
     const int pairs = co_tiles * a.ci_tiles;
     // Number of blocks: every block ends with one fp32-atomic merge of its 64 x 576 tile (measured ~0.17 us per block,
     // serialised: all blocks of a (co, ci) pair hit the same addresses), so time ~ F / (T r) + T m with r ~ 2.4 TFLOP/s per
     // block: T_opt = sqrt(F / (r m)) (scratch/bench_wgrad.py sweep, profiles/README.md), at most two blocks per CU.
-    static const int env_blocks = getenv("SP_WGRAD_ROWS_BLOCKS") ? atoi(getenv("SP_WGRAD_ROWS_BLOCKS")) : 0;
-    static const int env_slabs = getenv("SP_WGRAD_ROWS_SLABS") ? atoi(getenv("SP_WGRAD_ROWS_SLABS")) : 1;
+    const int env_blocks = sp_tune(SP_TUNE_WGRAD_ROWS_BLOCKS, 0);
+    const bool det = sp_deterministic(SP_BF16);
+    const int env_slabs = det ? 1 : sp_tune(SP_TUNE_WGRAD_ROWS_SLABS, 1);
     const bool use_slabs = env_slabs && ws != nullptr && ws_floats >= 512L * (9 * 64 * 64 + 64) && cin % 4 == 0 && (env_slabs == 1 || pairs <= env_slabs);
     const double flops = 2.0 * n * h * w * 9.0 * (64.0 * co_tiles) * (64.0 * a.ci_tiles);
     // with slabs the merge is a plain 147 KB store per block + one reduce pass (no serialisation): fill the chip
@@ -407,6 +412,8 @@ int sp_wgrad_rows_launch(const void* x, const void* dy, float* dw, float* dbias,
     a.rows_per_unit = ru;
     a.units = n * (w / 32) * (h / ru);
     int nblk = a.units < target ? a.units : target;
+    // the slab area holds 512 partial tiles; the deterministic mode must not fall back to atomics with several blocks per pair
+    if (det && (long)nblk * pairs > 512) nblk = 512 / pairs > 0 ? 512 / pairs : 1;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WR_LDS);
@@ -419,8 +426,8 @@ int sp_wgrad_rows_launch(const void* x, const void* dy, float* dw, float* dbias,
     if (a.slabs != nullptr) {
         int z = 512 / (36 * pairs);                       // ~512 reducer blocks
         if (z > nblk / 4) z = nblk / 4;
-        if (z < 1) z = 1;
-        hipLaunchKernelGGL(conv_wgrad_rows_reduce_kernel, dim3(9 * 64 * 16 / 256, (unsigned)pairs, (unsigned)z), dim3(256), 0, s, ws, nblk, dw, cin, cout, a.ci_tiles, a.bias_part, dbias);
+        if (z < 1 || det) z = 1;                          // deterministic mode: one ordered chain per element, no atomics
+        hipLaunchKernelGGL(conv_wgrad_rows_reduce_kernel, dim3(9 * 64 * 16 / 256, (unsigned)pairs, (unsigned)z), dim3(256), 0, s, ws, nblk, dw, cin, cout, a.ci_tiles, a.bias_part, dbias, det ? 1 : 0);
     }
     SP_LAUNCH_CHECK();
     return SP_OK;

@@ -140,7 +140,7 @@ __global__ void scale_add_kernel(const T* __restrict__ a, const T* __restrict__ 
 
 template <typename T>
 __global__ void scale_add_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ a, const float* __restrict__ g,
-                                     T* __restrict__ da, float* __restrict__ dg, long n4) {
+                                     T* __restrict__ da, float* __restrict__ dg_part, long n4) {
     __shared__ float red[4];
     const float gv = g[0];
     float part = 0.f;
@@ -153,7 +153,18 @@ __global__ void scale_add_bwd_kernel(const T* __restrict__ dy, const T* __restri
         Elem<T>::st4(da + i * 4, d);
     }
     const float tot = block_sum_256(part, red);
-    if (threadIdx.x == 0) atomicAdd(dg, tot);
+    if (threadIdx.x == 0) dg_part[blockIdx.x] = tot;          // column_sum_kernel adds the blocks in order
+}
+
+// out[col] = sum over rows of part[row][col], rows taken in a fixed order (the second stage of the reductions of this file:
+// per-block partial sums instead of atomics, so the results are bit-reproducible).  One block per column.
+__global__ __launch_bounds__(256) void column_sum_kernel(const float* __restrict__ part, int rows, int cols, float* __restrict__ out) {
+    __shared__ float red[4];
+    const int col = blockIdx.x;
+    float t = 0.f;
+    for (int r = threadIdx.x; r < rows; r += 256) t += part[(long)r * cols + col];
+    const float tot = block_sum_256(t, red);
+    if (threadIdx.x == 0) out[col] = tot;
 }
 
 // ---- (B, C*HW) <-> (B, HW*C) permutation (NCHW flatten order <-> NHWC) ------------------------------
@@ -172,7 +183,7 @@ __global__ void permute_kernel(const T* __restrict__ src, T* __restrict__ dst, i
 }
 
 // ---- per-channel sum over pixels (bias gradients) ---------------------------------------------------
-// thread = (4-channel group, pixel lane); pixel lanes are combined in LDS, then ONE atomic per (block, channel).
+// thread = (4-channel group, pixel lane); pixel lanes are combined in LDS, then one partial row per block (out = [blocks][C]).
 template <typename T>
 __global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ x, int ld, long pixels, int C,
                                                           float* __restrict__ out) {
@@ -205,7 +216,7 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ 
             for (int r = 0; r < 4 && c + r < C; ++r) {
                 float t = 0.f;
                 for (int k = 0; k < pix_par; ++k) t += red[(k * lanes_per_pix + cg) * 4 + r];
-                atomicAdd(out + c + r, t);
+                out[(long)blockIdx.x * C + c + r] = t;
             }
         }
     }
@@ -318,19 +329,18 @@ extern "C" int sp_scale_add(const void* a, const void* b, const float* g, void* 
     return SP_OK;
 }
 
-extern "C" int sp_scale_add_bwd(const void* dy, const void* a, const float* g, void* da, float* dg, int64_t numel,
+extern "C" int sp_scale_add_bwd(const void* dy, const void* a, const float* g, void* da, float* dg, float* partials, int64_t numel,
                                 int32_t dtype, sp_stream_t stream) {
-    SP_CHECK_ARG(dy && a && g && da && dg && numel % 4 == 0, "sp_scale_add_bwd: bad args");
+    SP_CHECK_ARG(dy && a && g && da && dg && partials && numel % 4 == 0, "sp_scale_add_bwd: bad args");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(dg, 0, sizeof(float), s);
-    if (e != hipSuccess) { sp_set_error("sp_scale_add_bwd: memset failed"); return SP_ERR_LAUNCH; }
-    // every block ends with ONE atomic on the same address: thousands of blocks serialise there (31 us for a 31 MB pass),
-    // 512 grid-striding blocks do not
+    // <= 512 grid-striding blocks, one partial sum each (thousands of blocks ending in one same-address atomic serialised
+    // there: 31 us for a 31 MB pass); the second kernel adds them in block order
     int gr = grid_for(numel / 4);
     if (gr > 512) gr = 512;
     SP_DT_SWITCH(dtype,
-                 hipLaunchKernelGGL(scale_add_bwd_kernel<float>, dim3(gr), dim3(256), 0, s, (const float*)dy, (const float*)a, g, (float*)da, dg, (long)(numel / 4)),
-                 hipLaunchKernelGGL(scale_add_bwd_kernel<bf16>, dim3(gr), dim3(256), 0, s, (const bf16*)dy, (const bf16*)a, g, (bf16*)da, dg, (long)(numel / 4)));
+                 hipLaunchKernelGGL(scale_add_bwd_kernel<float>, dim3(gr), dim3(256), 0, s, (const float*)dy, (const float*)a, g, (float*)da, partials, (long)(numel / 4)),
+                 hipLaunchKernelGGL(scale_add_bwd_kernel<bf16>, dim3(gr), dim3(256), 0, s, (const bf16*)dy, (const bf16*)a, g, (bf16*)da, partials, (long)(numel / 4)));
+    hipLaunchKernelGGL(column_sum_kernel, dim3(1), dim3(256), 0, s, partials, gr, 1, dg);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }
@@ -347,19 +357,18 @@ extern "C" int sp_permute_chw_hwc(const void* src, void* dst, int32_t batch, int
     return SP_OK;
 }
 
-extern "C" int sp_channel_sum(const void* x, int32_t ld, int64_t pixels, int32_t c, float* out, int32_t dtype,
+extern "C" int sp_channel_sum(const void* x, int32_t ld, int64_t pixels, int32_t c, float* out, float* partials, int32_t dtype,
                               sp_stream_t stream) {
-    SP_CHECK_ARG(x && out && ld >= c && c > 0, "sp_channel_sum: bad args");
+    SP_CHECK_ARG(x && out && partials && ld >= c && c > 0, "sp_channel_sum: bad args");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * c, s);
-    if (e != hipSuccess) { sp_set_error("sp_channel_sum: memset failed"); return SP_ERR_LAUNCH; }
     const int groups = (c + 3) / 4, lanes = groups < 256 ? groups : 256, pix_par = 256 / lanes;
     long blocks = pixels / ((long)pix_par * 32);
     if (blocks > 512) blocks = 512;
     if (blocks < 1) blocks = 1;
     SP_DT_SWITCH(dtype,
-                 hipLaunchKernelGGL(channel_sum_kernel<float>, dim3((int)blocks), dim3(256), 0, s, (const float*)x, ld, (long)pixels, c, out),
-                 hipLaunchKernelGGL(channel_sum_kernel<bf16>, dim3((int)blocks), dim3(256), 0, s, (const bf16*)x, ld, (long)pixels, c, out));
+                 hipLaunchKernelGGL(channel_sum_kernel<float>, dim3((int)blocks), dim3(256), 0, s, (const float*)x, ld, (long)pixels, c, partials),
+                 hipLaunchKernelGGL(channel_sum_kernel<bf16>, dim3((int)blocks), dim3(256), 0, s, (const bf16*)x, ld, (long)pixels, c, partials));
+    hipLaunchKernelGGL(column_sum_kernel, dim3(c), dim3(256), 0, s, partials, (int)blocks, c, out);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }

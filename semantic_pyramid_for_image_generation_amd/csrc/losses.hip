@@ -33,18 +33,17 @@ __global__ void dhead_fwd_kernel(const T* __restrict__ x, int ldx, const float* 
     }
 }
 
-// one block per sample b: dx row b, the embedding-gradient contribution of class row i = b and sdp[b] = sum_{i,c} dpred[i][b][c];
-// the LAST block to finish (ticket counter) forms dwc / dbc from all sdp (the first version let block 0 compute all B sums
-// itself - a serial chain of B*B*F/64 dependent loads, 55 of the kernel's 59 us)
-__device__ float g_dhead_sdp[1024];
-__device__ unsigned g_dhead_ticket;
+// one block per sample b: dx row b, the embedding-gradient row of class cls[b] and sdp[b] = sum_{i,c} dpred[i][b][c]; a second,
+// single-block kernel forms dwc / dbc from all sdp (a first version let block 0 compute all B sums itself - a serial chain of
+// B*B*F/64 dependent loads, 55 of the kernel's 59 us; a second one used a process-global "last block" ticket, which made the
+// entry point non-reentrant across streams).  sdp lives in caller scratch.
+// Embedding gradient without atomics: samples of the same class share a row of dE; the FIRST sample of a class sums the
+// contributions of all its samples in batch order and is the only writer of that row.
 template <typename T>
 __global__ void dhead_bwd_kernel(const float* __restrict__ dpred, const T* __restrict__ x, int ldx, const float* __restrict__ E,
                                  const int64_t* __restrict__ cls, const float* __restrict__ wc, T* __restrict__ dx, int lddx,
-                                 float* __restrict__ dE, float* __restrict__ dwc, float* __restrict__ dbc, int B, int F) {
-    extern __shared__ float sdp[];      // [B] (last block) ; [0..3] wave partials of this block's own sum
+                                 float* __restrict__ dE, float* __restrict__ sdp_out, int B, int F) {
     __shared__ float red[4];
-    __shared__ bool last;
     const int b = blockIdx.x;
     {
         float a = 0.f;
@@ -57,35 +56,40 @@ __global__ void dhead_bwd_kernel(const float* __restrict__ dpred, const T* __res
     }
     __syncthreads();
     const float sdp_b = red[0] + red[1] + red[2] + red[3];
+    const int64_t my_cls = cls[b];
+    bool first = true;
+    for (int i = 0; i < b; ++i) first = first && cls[i] != my_cls;      // block-uniform
     for (int c = threadIdx.x; c < F; c += 256) {
         float a = wc[c] * sdp_b;                               // dx[b][c]
         for (int i = 0; i < B; ++i) a += dpred[((long)i * B + b) * F + c] * E[cls[i] * F + c];
         Elem<T>::st(dx + (long)b * lddx + c, a);
-        float g = 0.f;                                         // dE[cls[b]][c] += sum_j dpred[b][j][c] * x[j][c]
-        for (int j = 0; j < B; ++j) g += dpred[((long)b * B + j) * F + c] * Elem<T>::ld(x + (long)j * ldx + c);
-        atomicAdd(dE + cls[b] * F + c, g);
+        if (first) {
+            float g = 0.f;                                     // dE[k][c] = sum_{i: cls[i] = k} sum_j dpred[i][j][c] * x[j][c]
+            for (int i = b; i < B; ++i) {
+                if (cls[i] != my_cls) continue;
+                for (int j = 0; j < B; ++j) g += dpred[((long)i * B + j) * F + c] * Elem<T>::ld(x + (long)j * ldx + c);
+            }
+            dE[my_cls * F + c] += g;
+        }
+    }
+    if (threadIdx.x == 0) sdp_out[b] = sdp_b;
+}
+
+template <typename T>
+__global__ void dhead_bwd_cls_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ sdp_in, float* __restrict__ dwc,
+                                     float* __restrict__ dbc, int B, int F) {
+    extern __shared__ float sdp[];      // [B]
+    for (int j = threadIdx.x; j < B; j += 256) sdp[j] = sdp_in[j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < F; c += 256) {
+        float a = 0.f;
+        for (int j = 0; j < B; ++j) a += Elem<T>::ld(x + (long)j * ldx + c) * sdp[j];
+        dwc[c] = a;
     }
     if (threadIdx.x == 0) {
-        g_dhead_sdp[b] = sdp_b;
-        __threadfence();
-        last = atomicAdd(&g_dhead_ticket, 1u) == (unsigned)(B - 1);
-    }
-    __syncthreads();
-    if (last) {
-        __threadfence();
-        for (int j = threadIdx.x; j < B; j += 256) sdp[j] = __builtin_nontemporal_load(&g_dhead_sdp[j]);
-        __syncthreads();
-        for (int c = threadIdx.x; c < F; c += 256) {
-            float a = 0.f;
-            for (int j = 0; j < B; ++j) a += Elem<T>::ld(x + (long)j * ldx + c) * sdp[j];
-            dwc[c] = a;
-        }
-        if (threadIdx.x == 0) {
-            float a = 0.f;
-            for (int j = 0; j < B; ++j) a += sdp[j];
-            dbc[0] = a;
-            g_dhead_ticket = 0;                                // ready for the next launch (same stream)
-        }
+        float a = 0.f;
+        for (int j = 0; j < B; ++j) a += sdp[j];
+        dbc[0] = a;
     }
 }
 
@@ -255,13 +259,18 @@ extern "C" int sp_dhead_fwd(const void* x, int32_t ldx, const float* emb_sn, con
 
 extern "C" int sp_dhead_bwd(const float* dpred, const void* x, int32_t ldx, const float* emb_sn, const int64_t* cls,
                             const float* wc, void* dx, int32_t lddx, float* demb, int32_t num_classes, float* dwc,
-                            float* dbc, int32_t batch, int32_t f, int32_t dtype, sp_stream_t stream) {
-    SP_CHECK_ARG(dpred && x && emb_sn && cls && wc && dx && demb && dwc && dbc && batch > 0 && batch <= 1024 && f > 0, "sp_dhead_bwd: bad args");
+                            float* dbc, float* scratch, int32_t batch, int32_t f, int32_t dtype, sp_stream_t stream) {
+    SP_CHECK_ARG(dpred && x && emb_sn && cls && wc && dx && demb && dwc && dbc && scratch && batch > 0 && batch <= 1024 && f > 0, "sp_dhead_bwd: bad args");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipError_t e = hipMemsetAsync(demb, 0, sizeof(float) * (size_t)num_classes * f, s);
     if (e != hipSuccess) { sp_set_error("sp_dhead_bwd: memset failed"); return SP_ERR_LAUNCH; }
-    if (dtype == SP_F32) hipLaunchKernelGGL(dhead_bwd_kernel<float>, dim3(batch), dim3(256), batch * 4, s, dpred, (const float*)x, ldx, emb_sn, cls, wc, (float*)dx, lddx, demb, dwc, dbc, batch, f);
-    else hipLaunchKernelGGL(dhead_bwd_kernel<bf16>, dim3(batch), dim3(256), batch * 4, s, dpred, (const bf16*)x, ldx, emb_sn, cls, wc, (bf16*)dx, lddx, demb, dwc, dbc, batch, f);
+    if (dtype == SP_F32) {
+        hipLaunchKernelGGL(dhead_bwd_kernel<float>, dim3(batch), dim3(256), 0, s, dpred, (const float*)x, ldx, emb_sn, cls, wc, (float*)dx, lddx, demb, scratch, batch, f);
+        hipLaunchKernelGGL(dhead_bwd_cls_kernel<float>, dim3(1), dim3(256), batch * 4, s, (const float*)x, ldx, scratch, dwc, dbc, batch, f);
+    } else {
+        hipLaunchKernelGGL(dhead_bwd_kernel<bf16>, dim3(batch), dim3(256), 0, s, dpred, (const bf16*)x, ldx, emb_sn, cls, wc, (bf16*)dx, lddx, demb, scratch, batch, f);
+        hipLaunchKernelGGL(dhead_bwd_cls_kernel<bf16>, dim3(1), dim3(256), batch * 4, s, (const bf16*)x, ldx, scratch, dwc, dbc, batch, f);
+    }
     SP_LAUNCH_CHECK();
     return SP_OK;
 }

@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
 // additions, so its length (rows / lanes) and the number of blocks (C / 8) decide the time, not the 64-byte row segments
 // (32 channels x 8 lanes: 9.4 us per launch, 33 launches per step).
 constexpr int FIN_CL = 8, FIN_NL = 256 / FIN_CL;
+constexpr int BN_EMB_MAXN = 256;         // largest batch of the conditional (class-embedding) backward
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nparts, long count, int C, float eps,
                                                           float momentum, float* __restrict__ running_mean,
                                                           float* __restrict__ running_var, int training,
@@ -253,6 +254,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ demb, int num_classes) {
     __shared__ double red[256 * 4];
+    __shared__ float embv[BN_EMB_MAXN][FIN_CL][2];       // per-sample (dscale, dbias) of this block's channels
     const int cl = threadIdx.x % FIN_CL, bl = threadIdx.x / FIN_CL;
     const int c = blockIdx.x * FIN_CL + cl;
     if (demb) {
@@ -276,11 +278,18 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
             s2 += sc * b;
             ga += b;
             gb += a;
-            if (demb) {
-                atomicAdd(demb + (long)aff.cls[n] * 2 * C + c, (float)b);
-                atomicAdd(demb + (long)aff.cls[n] * 2 * C + C + c, (float)a);
-            }
+            if (demb) { embv[n][cl][0] = (float)b; embv[n][cl][1] = (float)a; }
         }
+    }
+    if (demb) {
+        // samples of one class share a row: one thread per channel adds them in batch order (no atomics, reproducible)
+        __syncthreads();
+        if (bl == 0 && c < C)
+            for (int n = 0; n < N; ++n) {
+                float* row = demb + (long)aff.cls[n] * 2 * C;
+                row[c] += embv[n][cl][0];
+                row[C + c] += embv[n][cl][1];
+            }
     }
     red[threadIdx.x * 4] = s1; red[threadIdx.x * 4 + 1] = s2; red[threadIdx.x * 4 + 2] = ga; red[threadIdx.x * 4 + 3] = gb;
     __syncthreads();
@@ -414,6 +423,7 @@ extern "C" int sp_bn_backward(const void* dy, const void* x, void* dx, int32_t n
                               sp_stream_t stream) {
     SP_CHECK_ARG(dy && x && dx && mean && invstd && partials && c_tmp && c % 4 == 0, "sp_bn_backward: bad args");
     SP_CHECK_ARG(!emb || (cls && (!demb || num_classes > 0)), "sp_bn_backward: conditional mode needs class indices");
+    SP_CHECK_ARG(!demb || n <= BN_EMB_MAXN, "sp_bn_backward: the conditional backward supports batches up to %d", BN_EMB_MAXN);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     Affine aff{gamma, beta, emb, cls};
     const int v = (dtype == SP_BF16 && c % 8 == 0) ? 8 : 4;

@@ -6,7 +6,7 @@
 // beyond a layer's extent exit immediately (ragged batch without a block map).
 //
 // Per-call scratch (fp32, offsets from the table): t[cols] (becomes the v snapshot), s[rows] (= W v),
-// usnap[rows], scal[4] = {sigma, 1/sigma, -, -}.  The snapshots are what the backward of THIS forward
+// usnap[rows], scal[4] = {sigma, 1/sigma, -, -}; at part_off: ceil(rows/128) x cols partial sums of W^T u.  The snapshots are what the backward of THIS forward
 // needs: the discriminator runs 2-3 forwards (each with its own power iteration) before a backward.
 #include "common.h"
 
@@ -14,21 +14,33 @@ namespace {
 
 constexpr float SN_EPS = 1e-12f;
 
-// phase 1: t[c] += sum_{r in row slab} W[r][c] * u[r]        (scratch pre-zeroed)
+// phase 1a: part[z][c] = sum_{r in row slab z} W[r][c] * u[r]   (one 128-row slab per blockIdx.z; plain stores)
+constexpr int SN_SLAB = 128;
 __global__ __launch_bounds__(256) void sn_wtu_kernel(const sp_sn_layer* __restrict__ table, float* __restrict__ scratch) {
     const sp_sn_layer L = table[blockIdx.y];
     const int c = blockIdx.x * 256 + threadIdx.x;
-    const int r0 = blockIdx.z * 128;
+    const int r0 = blockIdx.z * SN_SLAB;
     if (blockIdx.x * 256 >= L.cols || r0 >= L.rows) return;
-    __shared__ float us[128];
-    const int r1 = min(r0 + 128, L.rows);
+    __shared__ float us[SN_SLAB];
+    const int r1 = min(r0 + SN_SLAB, L.rows);
     if (threadIdx.x < r1 - r0) us[threadIdx.x] = L.u[r0 + threadIdx.x];
     __syncthreads();
     if (c >= L.cols) return;
     float acc = 0.f;
     const float* w = L.w + (long)r0 * L.cols + c;
     for (int r = 0; r < r1 - r0; ++r) acc += w[(long)r * L.cols] * us[r];
-    atomicAdd(scratch + L.scratch_off + c, acc);
+    scratch[L.part_off + (long)blockIdx.z * L.cols + c] = acc;
+}
+// phase 1b: t[c] = sum_z part[z][c] in slab order (the atomics this replaces made even the forward pass vary run to run)
+__global__ __launch_bounds__(256) void sn_tsum_kernel(const sp_sn_layer* __restrict__ table, float* __restrict__ scratch) {
+    const sp_sn_layer L = table[blockIdx.y];
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= L.cols) return;
+    const int nz = (L.rows + SN_SLAB - 1) / SN_SLAB;
+    const float* part = scratch + L.part_off + c;
+    float t = 0.f;
+    for (int z = 0; z < nz; ++z) t += part[(long)z * L.cols];
+    scratch[L.scratch_off + c] = t;
 }
 
 // phase 2: one wave per row: s[r] = W[r] . v  with v = t / max(||t||, eps) (power iteration) or the
@@ -208,8 +220,9 @@ __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const float* __restri
 // ---- backward, batched over the layers of one network (one launch pair per backward pass instead of one per layer):
 // grid.y = layer, blocks past a layer's extent exit.  dots are zero-filled by the caller (they live in the same arena as
 // the dW slots, which the caller zero-fills once per backward pass).
-__global__ __launch_bounds__(256) void sn_bwd_dot_batched_kernel(const sp_sn_bwd_layer* __restrict__ table, float* __restrict__ arena,
-                                                                 const float* __restrict__ scratch) {
+constexpr int SN_DOT_BLOCKS = 512;      // blocks (= partial sums) per layer of the batched dot kernel
+__global__ __launch_bounds__(256) void sn_bwd_dot_batched_kernel(const sp_sn_bwd_layer* __restrict__ table, const float* __restrict__ arena,
+                                                                 float* __restrict__ dot_partials) {
     const sp_sn_bwd_layer L = table[blockIdx.y];
     const long total = (long)L.rows * L.cols;
     const long nb = min((long)gridDim.x, (total + 1023) / 1024);      // blocks working on this layer
@@ -227,12 +240,12 @@ __global__ __launch_bounds__(256) void sn_bwd_dot_batched_kernel(const sp_sn_bwd
         part += dwsn[src] * L.w[e];
     }
     const float tot = block_sum_256(part, red);
-    if (threadIdx.x == 0) atomicAdd(arena + L.dot_off, tot);
+    if (threadIdx.x == 0) dot_partials[(long)blockIdx.y * SN_DOT_BLOCKS + blockIdx.x] = tot;     // summed in block order by the apply kernel
 }
 
 __global__ __launch_bounds__(256) void sn_bwd_apply_batched_kernel(const sp_sn_bwd_layer* __restrict__ table, const float* __restrict__ arena,
                                                                    const float* __restrict__ scratch, float* grads, const float* prev,
-                                                                   float* bias_grads) {
+                                                                   float* bias_grads, const float* __restrict__ dot_partials) {
     const sp_sn_bwd_layer L = table[blockIdx.y];
     if (bias_grads != nullptr && blockIdx.x == 0) {            // bias gradients: plain sums, copied / added as they are
         for (int r = threadIdx.x; r < L.rows; r += 256) {
@@ -243,11 +256,16 @@ __global__ __launch_bounds__(256) void sn_bwd_apply_batched_kernel(const sp_sn_b
     const long total = (long)L.rows * L.cols;
     const long nb = min((long)gridDim.x, (total + 1023) / 1024);
     if ((long)blockIdx.x >= nb) return;
+    // <dwsn, W>: the layer's per-block partial sums, added in the same order by every block (no atomics, no zero fill)
+    __shared__ float red[4];
+    float dpart = 0.f;
+    for (long k = threadIdx.x; k < nb; k += 256) dpart += dot_partials[(long)blockIdx.y * SN_DOT_BLOCKS + k];
+    const float dot = block_sum_256(dpart, red);
     const float* dwsn = arena + L.dw_off;
     const float* vsnap = scratch + L.scratch_off;
     const float* usnap = vsnap + L.cols + L.rows;
     const float inv_sigma = usnap[L.rows + 1];
-    const float coef = arena[L.dot_off] * inv_sigma;       // <dwsn, W/sigma>
+    const float coef = dot * inv_sigma;                    // <dwsn, W/sigma>
     float* grad = grads + L.grad_off;
     const float* acc = prev ? prev + L.grad_off : nullptr;    // may alias grad: every element is read, then written, by one thread
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += nb * 256) {
@@ -312,10 +330,9 @@ extern "C" int sp_sn_forward(const sp_sn_layer* table_dev, int32_t n_layers, int
     SP_CHECK_ARG(dtype == SP_F32 || dtype == SP_BF16, "sp_sn_forward: bad dtype %d", dtype);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (power_iter) {
-        hipError_t e = hipMemsetAsync(scratch, 0, sizeof(float) * (size_t)scratch_floats, s);
-        if (e != hipSuccess) { sp_set_error("sp_sn_forward: memset failed: %s", hipGetErrorString(e)); return SP_ERR_LAUNCH; }
-        hipLaunchKernelGGL(sn_wtu_kernel, dim3(sp_div_up(max_cols, 256), n_layers, sp_div_up(max_rows, 128)), dim3(256), 0, s,
+        hipLaunchKernelGGL(sn_wtu_kernel, dim3(sp_div_up(max_cols, 256), n_layers, sp_div_up(max_rows, SN_SLAB)), dim3(256), 0, s,
                            table_dev, scratch);
+        hipLaunchKernelGGL(sn_tsum_kernel, dim3(sp_div_up(max_cols, 256), n_layers), dim3(256), 0, s, table_dev, scratch);
         SP_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(sn_wv_kernel, dim3(sp_div_up(max_rows, 4), n_layers), dim3(256), 0, s, table_dev, scratch, power_iter);
@@ -363,14 +380,15 @@ extern "C" int sp_sn_backward(const float* dwsn, const float* w_orig, const floa
 
 extern "C" int sp_sn_backward_batched(const sp_sn_bwd_layer* table_dev, int32_t n_layers, int64_t max_elems, float* arena,
                                       const float* scratch, float* grads, const float* accumulate_from, float* bias_grads,
-                                      sp_stream_t stream) {
-    SP_CHECK_ARG(table_dev && arena && scratch && grads && n_layers > 0 && max_elems > 0, "sp_sn_backward_batched: bad args");
+                                      float* dot_partials, sp_stream_t stream) {
+    SP_CHECK_ARG(table_dev && arena && scratch && grads && dot_partials && n_layers > 0 && max_elems > 0, "sp_sn_backward_batched: bad args");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int bx = (int)((max_elems + 1023) / 1024);
-    if (bx > 512) bx = 512;
+    if (bx > SN_DOT_BLOCKS) bx = SN_DOT_BLOCKS;
     dim3 grid(bx, n_layers);
-    hipLaunchKernelGGL(sn_bwd_dot_batched_kernel, grid, dim3(256), 0, s, table_dev, arena, scratch);
-    hipLaunchKernelGGL(sn_bwd_apply_batched_kernel, grid, dim3(256), 0, s, table_dev, arena, scratch, grads, accumulate_from, bias_grads);
+    hipLaunchKernelGGL(sn_bwd_dot_batched_kernel, grid, dim3(256), 0, s, table_dev, arena, dot_partials);
+    hipLaunchKernelGGL(sn_bwd_apply_batched_kernel, grid, dim3(256), 0, s, table_dev, arena, scratch, grads, accumulate_from, bias_grads,
+                       dot_partials);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }

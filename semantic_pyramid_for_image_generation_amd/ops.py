@@ -189,8 +189,9 @@ class _SNBankFn(torch.autograd.Function):
             # parameters' .grad are views of them - autograd neither sums nor stores anything for these parameters
             bank.enter_backward(call.arena.device)
             prev = bank.flat_w if bank.win_count > 0 else None
+            dots = torch.empty(n * 512, dtype=torch.float32, device=call.arena.device)     # per-block partial <dW, W> sums
             L.call("sp_sn_backward_batched", ptr(bank.bwd_table_dev), n, bank.max_elems, ptr(call.arena), ptr(call.scratch),
-                   ptr(bank.flat_w), ptr(prev), ptr(bank.flat_b), stream())
+                   ptr(bank.flat_w), ptr(prev), ptr(bank.flat_b), ptr(dots), stream())
             bank.win_count += 1
             bank.win_touched |= call.touched
             bank.win_bias |= call.bias_touched
@@ -201,8 +202,9 @@ class _SNBankFn(torch.autograd.Function):
                     m.bias.grad = bank.b_views[i]
             return (None,) * (n + 1)
         grads = torch.empty(bank.grad_floats, dtype=torch.float32, device=call.arena.device)
+        dots = torch.empty(n * 512, dtype=torch.float32, device=call.arena.device)
         L.call("sp_sn_backward_batched", ptr(bank.bwd_table_dev), n, bank.max_elems, ptr(call.arena), ptr(call.scratch),
-               ptr(grads), None, None, stream())
+               ptr(grads), None, None, ptr(dots), stream())
         out = [None]
         for i, (m, _, _) in enumerate(bank.specs):
             if i in call.touched and ctx.needs_input_grad[i + 1]:
@@ -276,6 +278,8 @@ class SpectralNormBank:
             ent.kind = 1 if kind == "plain" else 0
             ent.scratch_off = scratch_off
             scratch_off += pad_to(cols + 2 * rows + 4, 4)
+            ent.part_off = scratch_off                    # ceil(rows/128) x cols partial sums of W^T u (summed in slab order)
+            scratch_off += pad_to(((rows + 127) // 128) * cols, 4)
             fwd_bytes = rows * cols * 4 if kind == "plain" else rows * taps * cin_p * esz
             ent.fwd_off = pack_off
             pack_off += pad_to(fwd_bytes, 256)
@@ -380,7 +384,7 @@ def _is_halo128(n, h, w, cout, ksize) -> bool:
     return True
 
 
-TUNE_CONV_TALL, TUNE_IGEMM_DMA, TUNE_WGRAD_ROWS = 0, 1, 2
+TUNE_CONV_TALL, TUNE_IGEMM_DMA, TUNE_WGRAD_ROWS, TUNE_DETERMINISTIC = 0, 1, 2, 3
 _POOL2_BWD_FUSED = os.environ.get("SP_POOL2_BWD_FUSED", "1") == "1"     # A/B switch (profiles/README.md)
 
 
@@ -388,6 +392,7 @@ def set_tuning(key: int, value: int) -> None:
     """Kernel-selection knob of the library (include/sempyr.h: sp_set_tuning); value < 0 restores the default."""
     L.call("sp_set_tuning", key, value)
     _CONV_WS_CACHE.clear()
+    _WS_CACHE.clear()
 
 
 def conv_launch(x, w_ptr: int, bias, y, res1, res2, mask_src, slope: float, n, h, w, cin_p, cout, ldy, ksize, act,
@@ -539,7 +544,8 @@ class _ConvFn(torch.autograd.Function):
         elif bias_needed(need, 2):
             db = torch.empty(cout, dtype=torch.float32, device=x.device)
             pooled = 4 if up2 else 1      # the bias gradient is the plain sum of the pooled gradient (4 x 1/4)
-            L.call("sp_channel_sum", ptr(dz), cout_p, n * h * w // pooled, cout, ptr(db), sp_dtype(dt), stream())
+            part = torch.empty(512 * cout, dtype=torch.float32, device=x.device)
+            L.call("sp_channel_sum", ptr(dz), cout_p, n * h * w // pooled, cout, ptr(db), ptr(part), sp_dtype(dt), stream())
         if (ctx.has_res[0] and need[3]) or (ctx.has_res[1] and need[4]):
             if dres is None:
                 raise L.SempyrError("residual gradient with padded channels is not supported")
@@ -869,7 +875,8 @@ class _ScaleAddFn(torch.autograd.Function):
         dy = as_nhwc(dy, a.dtype)
         da = torch.empty_like(a)
         dg = torch.empty(1, dtype=torch.float32, device=a.device)
-        L.call("sp_scale_add_bwd", ptr(dy), ptr(a), ptr(gamma), ptr(da), ptr(dg), a.numel(), sp_dtype(a.dtype), stream())
+        part = torch.empty(512, dtype=torch.float32, device=a.device)
+        L.call("sp_scale_add_bwd", ptr(dy), ptr(a), ptr(gamma), ptr(da), ptr(dg), ptr(part), a.numel(), sp_dtype(a.dtype), stream())
         return da, dy, dg
 
 
@@ -993,12 +1000,25 @@ class _AttentionFn(torch.autograd.Function):
         n, nk = hq * wq, hk * wk
         do = as_nhwc(do, q.dtype)
         dq, dk, dvv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        nqb = (n + 63) // 64                       # scratch: one partial slab per 64-query block (include/sempyr.h)
+        nqb = _attention_slabs(n, nk, d, dv, q.dtype)   # scratch: one partial slab per query block (include/sempyr.h)
         dk32 = torch.empty(nqb * b * nk * d, dtype=torch.float32, device=q.device)
         dv32 = torch.empty(nqb * b * nk * dv, dtype=torch.float32, device=q.device)
         L.call("sp_attention_bwd", ptr(q), ptr(k), ptr(v), ptr(do), ptr(lse), ptr(dq), ptr(dk32), ptr(dv32), ptr(dk), ptr(dvv),
                b, n, nk, d, dv, sp_dtype(q.dtype), stream())
         return dq, dk, dvv
+
+
+_ATTN_SLABS = {}
+
+
+def _attention_slabs(n, nk, d, dv, dtype) -> int:
+    key = (n, nk, d, dv, dtype)
+    v = _ATTN_SLABS.get(key)
+    if v is None:
+        out = ctypes.c_int64(0)
+        L.call("sp_attention_bwd_slabs", n, nk, d, dv, sp_dtype(dtype), ctypes.byref(out))
+        v = _ATTN_SLABS[key] = int(out.value)
+    return v
 
 
 def attention_core(q, k, v):
@@ -1035,8 +1055,9 @@ class _DHeadFn(torch.autograd.Function):
         demb_sn = pl_emb.call.dw_slot(pl_emb) if need[1] else torch.empty(pl_emb.rows * pl_emb.cols, dtype=torch.float32, device=dev)
         dwc_sn = pl_cls.call.dw_slot(pl_cls) if need[2] else torch.empty(f, dtype=torch.float32, device=dev)
         dbc = torch.empty(1, dtype=torch.float32, device=dev)
+        sdp = torch.empty(b, dtype=torch.float32, device=dev)             # per-sample sums between the call's two kernels
         L.call("sp_dhead_bwd", ptr(dpred), ptr(x), x.stride(0), ctypes.c_void_p(pl_emb.fwd), ptr(cls), ctypes.c_void_p(pl_cls.fwd),
-               ptr(dx), dx.stride(0), ptr(demb_sn), pl_emb.rows, ptr(dwc_sn), ptr(dbc), b, f, sp_dtype(x.dtype), stream())
+               ptr(dx), dx.stride(0), ptr(demb_sn), pl_emb.rows, ptr(dwc_sn), ptr(dbc), ptr(sdp), b, f, sp_dtype(x.dtype), stream())
         z = _zero1(dev)
         return dx, (z if need[1] else None), (z if need[2] else None), (dbc if need[3] else None), None, None, None
 

@@ -1,0 +1,153 @@
+"""Per-block golden vectors (rows a4-a9, a12-a14 at tiny shapes, FULL tensors) from the UNMODIFIED reference.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_block_golden.py
+
+Every block of /root/reference/models.py and every loss of /root/reference/lossfunction.py is instantiated on its own,
+given the reference-free synthetic parameters of ``semantic_pyramid_for_image_generation_amd.params``, run forward on seeded
+inputs in training mode and backward against a seeded output gradient.  Recorded per case: the inputs, the output, the input
+gradients, every parameter gradient and the buffers the forward mutates (spectral-norm u / v after the power iteration,
+BatchNorm running statistics).  Only data is written (tests/golden/blocks.npz + blocks.json); no reference source is copied.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import reference_stubs  # noqa: E402
+from semantic_pyramid_for_image_generation_amd import params  # noqa: E402
+
+CLASSES = 5
+
+
+def rnd(*shape, seed):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+def onehot(idx, n=CLASSES):
+    return torch.nn.functional.one_hot(torch.tensor(idx), n)
+
+
+def cases(models, lossfunction):
+    """name -> (constructor, kwargs, list of (input name, tensor, differentiable), call)"""
+    bern = lambda *shape, seed: (torch.rand(*shape, generator=torch.Generator().manual_seed(seed)) < 0.6).float()   # noqa: E731
+    return {
+        # a4
+        "linear_block": (lambda: models.LinearBlock(in_features=16, out_features=24, feature_size=40),
+                         [("input", rnd(3, 16, seed=1), True), ("masked_features", rnd(3, 40, seed=2) * bern(3, 40, seed=3), False)],
+                         lambda m, i: m(i["input"], i["masked_features"])),
+        # a5 (feature_channels counts the concatenated mask channel, models.py:94)
+        "generator_residual_block": (lambda: models.GeneratorResidualBlock(in_channels=16, out_channels=8, feature_channels=9,
+                                                                            number_of_classes=CLASSES),
+                                     [("input", rnd(2, 16, 4, 4, seed=4), True),
+                                      ("masked_features", torch.cat([rnd(2, 8, 8, 8, seed=5) * bern(2, 1, 8, 8, seed=6), bern(2, 1, 8, 8, seed=6)], 1), False),
+                                      ("class_id", onehot([3, 1]).float(), False)],
+                                     lambda m, i: m(i["input"], i["masked_features"], i["class_id"])),
+        # a6 (two samples share a class: their embedding-row gradients add up)
+        "conditional_batch_norm": (lambda: models.ConditionalBatchNorm(num_features=8, number_of_classes=CLASSES),
+                                   [("input", rnd(3, 8, 4, 4, seed=7), True), ("class_id", onehot([2, 0, 2]).float(), False)],
+                                   lambda m, i: m(i["input"], i["class_id"])),
+        # a7
+        "self_attention": (lambda: models.SelfAttention(channels=32),
+                           [("input", rnd(2, 32, 8, 8, seed=8), True)],
+                           lambda m, i: m(i["input"])),
+        # a9
+        "discriminator_input_residual_block": (lambda: models.DiscriminatorInputResidualBlock(in_channels=3, out_channels=8),
+                                               [("input", rnd(2, 3, 16, 16, seed=9), True)],
+                                               lambda m, i: m(i["input"])),
+        "discriminator_residual_block": (lambda: models.DiscriminatorResidualBlock(in_channels=8, out_channels=16),
+                                         [("input", rnd(2, 8, 8, 8, seed=10), True)],
+                                         lambda m, i: m(i["input"])),
+    }
+
+
+def run_block(name, ctor, inputs, call, arrays, meta):
+    torch.manual_seed(0)
+    m = ctor()
+    sd = params.synth_state_dict(m.state_dict(), 40)
+    m.load_state_dict(sd)
+    m.train()
+    ins = {}
+    for key, t, diff in inputs:
+        ins[key] = t.clone().requires_grad_(diff)
+        arrays["%s/in/%s" % (name, key)] = t.numpy()
+    out = call(m, ins)
+    gy = rnd(*out.shape, seed=99)
+    out.backward(gy)
+    arrays["%s/out" % name] = out.detach().numpy()
+    arrays["%s/gout" % name] = gy.numpy()
+    for key, t, diff in inputs:
+        if diff:
+            arrays["%s/gin/%s" % (name, key)] = ins[key].grad.numpy()
+    for k, v in sd.items():
+        arrays["%s/param/%s" % (name, k)] = v.numpy()
+    for k, p in m.named_parameters():
+        arrays["%s/grad/%s" % (name, k)] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+    for k, v in m.state_dict().items():
+        if k.endswith(("weight_u", "weight_v", "running_mean", "running_var", "num_batches_tracked")):
+            arrays["%s/buf/%s" % (name, k)] = v.numpy()
+    meta[name] = {"inputs": [k for k, _, _ in inputs], "diff_inputs": [k for k, _, d in inputs if d],
+                  "state_keys": list(sd.keys()), "param_names": [k for k, _ in m.named_parameters()]}
+
+
+def run_losses(lossfunction, arrays, meta):
+    # a12
+    pr, pf = rnd(3, 3, 8, seed=11).requires_grad_(True), rnd(3, 3, 8, seed=12).requires_grad_(True)
+    lr, lf = lossfunction.LSGANDiscriminatorLoss()(pr, pf)
+    (lr + lf).backward()
+    pg = rnd(3, 3, 8, seed=13).requires_grad_(True)
+    lg = lossfunction.LSGANGeneratorLoss()(pg)
+    lg.backward()
+    for k, v in (("pred_real", pr), ("pred_fake", pf), ("pred_gen", pg)):
+        arrays["lsgan/in/" + k] = v.detach().numpy()
+        arrays["lsgan/gin/" + k] = v.grad.numpy()
+    arrays["lsgan/out"] = np.array([float(lr), float(lf), float(lg)], dtype=np.float32)
+    # a13: 5 spatial levels + the two vector levels, as the pyramid has them (tiny extents)
+    shapes = [(2, 4, 16, 16), (2, 6, 8, 8), (2, 8, 4, 4), (2, 8, 2, 2), (2, 4, 2, 2), (2, 24), (2, 10)]
+    real = [rnd(*s, seed=20 + i) for i, s in enumerate(shapes)]
+    fake = [rnd(*s, seed=30 + i).requires_grad_(True) for i, s in enumerate(shapes)]
+    masks = [(torch.rand(s[0], 1, *s[2:], generator=torch.Generator().manual_seed(40 + i)) < 0.5).float() if len(s) == 4
+             else (torch.rand(*s, generator=torch.Generator().manual_seed(40 + i)) < 0.5).float() for i, s in enumerate(shapes)]
+    loss = lossfunction.SemanticReconstructionLoss()(real, fake, masks)
+    loss.backward(torch.ones_like(loss))
+    arrays["rec/out"] = loss.detach().numpy()
+    for i in range(len(shapes)):
+        arrays["rec/in/real%d" % i] = real[i].numpy()
+        arrays["rec/in/fake%d" % i] = fake[i].detach().numpy()
+        arrays["rec/in/mask%d" % i] = masks[i].numpy()
+        arrays["rec/gin/fake%d" % i] = fake[i].grad.numpy()
+    # a14
+    img, z = rnd(4, 3, 8, 8, seed=50).requires_grad_(True), rnd(4, 16, seed=51)
+    ld = lossfunction.DiversityLoss()(img, z)
+    ld.backward()
+    arrays["div/in/images"] = img.detach().numpy()
+    arrays["div/in/latents"] = z.numpy()
+    arrays["div/out"] = np.array([float(ld)], dtype=np.float32)
+    arrays["div/gin/images"] = img.grad.numpy()
+    meta["losses"] = {"rec_levels": len(shapes)}
+
+
+def main():
+    models, lossfunction, _, _ = reference_stubs.import_reference()
+    torch.set_num_threads(1)
+    arrays, meta = {}, {"torch": torch.__version__, "classes": CLASSES}
+    for name, (ctor, inputs, call) in cases(models, lossfunction).items():
+        run_block(name, ctor, inputs, call, arrays, meta)
+    run_losses(lossfunction, arrays, meta)
+    np.savez_compressed(os.path.join(HERE, "blocks.npz"), **arrays)
+    with open(os.path.join(HERE, "blocks.json"), "w") as f:
+        json.dump(meta, f, indent=0)
+    print("blocks:", sorted(k for k in meta if k not in ("torch", "classes")), "arrays:", len(arrays),
+          "bytes:", os.path.getsize(os.path.join(HERE, "blocks.npz")))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,105 @@
+"""BASELINE.json configurations beyond the benchmark's own (C2 = batch 32, C4 = channel_factor 2 and - the
+wide net that stresses the 3x3 backward tiles - channel_factor 0.5).  ``channel_factor`` DIVIDES the widths
+(/root/reference/models.py:34,38-48,117-128): cf=2 gives 32-channel layers (below the pooling-epilogue rule cout > 32),
+cf=0.5 gives 1024 / 1536-channel layers (beyond the direct 1x1 kernel's Cin <= 1024).  Each configuration is held to
+  * whole-network forwards against the CPU oracle in the fp32 parity mode (1e-3), and
+  * one full D+G training step in the bf16 throughput mode, checked through size-independent properties.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import golden_util as gu  # noqa: E402
+from oracle import sempyr_oracle as O  # noqa: E402
+import semantic_pyramid_for_image_generation_amd as sp  # noqa: E402
+from semantic_pyramid_for_image_generation_amd import ops, synthetic  # noqa: E402
+
+LOSS_NAMES = ("loss_discriminator_real", "loss_discriminator_fake", "loss_generator",
+              "loss_generator_semantic_reconstruction", "loss_generator_diversity")
+
+
+@pytest.fixture(autouse=True)
+def _dtype_reset():
+    yield
+    ops.set_compute_dtype(torch.float32)
+
+
+def build(cf, seed, device="cuda"):
+    meta = {"cf": cf, "seed": seed}
+    Gsd, Dsd, Vsd = gu.synth_states(meta)
+    G = sp.Generator(channels_factor=cf); D = sp.Discriminator(channel_factor=cf); V = sp.VGG16()
+    G.load_state_dict(Gsd); D.load_state_dict(Dsd); V.load_state_dict(Vsd)
+    return (G.to(device), D.to(device), V.to(device).eval()), (Gsd, Dsd, Vsd)
+
+
+@pytest.mark.parametrize("cf", [2, 0.5])
+def test_channel_factor_forward_vs_oracle_fp32(cf):
+    """G and D forwards at channel_factor 2 / 0.5 vs the oracle on identical parameters and inputs (fp32 mode, B=2)."""
+    ops.set_compute_dtype(torch.float32)
+    (G, D, V), (Gsd, Dsd, Vsd) = build(cf, 21)
+    oG, oD, oV = O.make_state(Gsd), O.make_state(Dsd), O.make_state(Vsd, frozen=True)
+    images, labels, masks = gu.golden_batches(2, 6)[0]
+    z = torch.randn(2, 128, generator=torch.Generator().manual_seed(8))
+    with torch.no_grad():
+        fr = O.vgg16_forward(oV, images)
+        ref_img = O.generator_forward(oG, z, fr, masks, labels.float(), True)
+        ref_pred = O.discriminator_forward(oD, ref_img, labels, True)
+        feats = V(images.cuda())
+        img = G(input=z.cuda(), features=feats, masks=[m.cuda() for m in masks], class_id=labels.float().cuda())
+        pred = D(ref_img.cuda(), labels.cuda())
+    assert tuple(img.shape) == (2, 3, 256, 256) and tuple(pred.shape) == (2, 2, 128)
+    err = float((img.float().cpu() - ref_img).abs().max())
+    assert err <= 1e-3 * 2.0, err
+    perr = float((pred.float().cpu() - ref_pred).abs().max() / ref_pred.abs().max())
+    assert perr <= 1e-3, perr
+
+
+def property_step(cf, batch, seed, dtype):
+    ops.set_compute_dtype(dtype)
+    (G, D, V), _ = build(cf, seed)
+    before_g = {k: v.clone() for k, v in G.state_dict().items()}
+    before_d = {k: v.clone() for k, v in D.state_dict().items()}
+    opt_g = sp.optim.Adam(G.parameters(), lr=1e-4)
+    opt_d = sp.optim.Adam(D.parameters(), lr=1e-4)
+    mw = sp.ModelWrapper(generator=G, discriminator=D, vgg16=V, training_dataset=None, validation_dataset=None,
+                         generator_optimizer=opt_g, discriminator_optimizer=opt_d, save_data_path=None)
+    G.train(); D.train()
+    images, labels, masks = synthetic.synthetic_batch(batch, 31)
+    torch.manual_seed(5)
+    out = mw.train_step(images.cuda(), labels.cuda(), [m.cuda() for m in masks])
+    for n in LOSS_NAMES:
+        v = float(out[n])
+        assert np.isfinite(v) and 0.0 <= v < 10.0, (n, v)
+    img = out["images_fake"].float()
+    assert tuple(img.shape) == (batch, 3, 256, 256)
+    assert float(img.abs().max()) <= 1.0 and bool(torch.isfinite(img).all())
+    for net, before in ((G, before_g), (D, before_d)):
+        after = net.state_dict()
+        moved = 0
+        for k in before:
+            assert bool(torch.isfinite(after[k].float()).all()), k
+            if k.endswith("weight_u") or k.endswith("weight_v"):
+                assert abs(float(after[k].norm()) - 1.0) < 1e-3, k
+            if k.endswith("weight_orig") and not torch.equal(before[k], after[k]):
+                # Adam's first step moves every element with a non-zero gradient by at most lr
+                assert float((after[k] - before[k]).abs().max()) <= 1.0001e-4, k
+                moved += 1
+        assert moved >= 20, moved
+    return out
+
+
+@pytest.mark.parametrize("cf", [2, 0.5])
+def test_channel_factor_step_properties_bf16(cf):
+    property_step(cf, 4, 17, torch.bfloat16)
+
+
+def test_batch_32_step_properties_bf16():
+    """BASELINE.json config 2: one MI355X, bf16, batch 32, channel_factor 1."""
+    property_step(1, 32, 19, torch.bfloat16)
+
+
+def test_batch_20_step_properties_bf16():
+    """The benchmark's own shape (batch 20 per GPU, channel_factor 1) outside bench.py."""
+    property_step(1, 20, 23, torch.bfloat16)

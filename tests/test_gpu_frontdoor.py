@@ -1,0 +1,103 @@
+"""The drop-in boundary through the front door: exactly what /root/reference/main.py:52-107 does.
+
+``compat/`` goes first on ``sys.path``; ``from models import Generator, Discriminator, VGG16`` and
+``from model_wrapper import ModelWrapper`` then resolve to the MI355X implementation, while ``data`` / ``misc`` stay the
+CALLER'S modules (compat/ does not shadow them: main.py:80-88 needs the caller's ``data.Places365``).  The objects are
+built as main.py:58-65,91-103 builds them - ``.cuda()``, ``load_state_dict``, plain ``torch.optim.Adam``, ``nn.DataParallel``
+wrappers - and ``ModelWrapper.train(epochs=1, device='cuda')`` runs over the two golden batches; the metrics its Logger
+collects are compared with the ones the unmodified reference logged for the same loop (tests/golden/make_golden.py).
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+import golden_util as gu  # noqa: E402
+from semantic_pyramid_for_image_generation_amd import ops  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMPAT = os.path.join(ROOT, "compat")
+LOSS_NAMES = ("loss_discriminator_real", "loss_discriminator_fake", "loss_generator",
+              "loss_generator_semantic_reconstruction", "loss_generator_diversity")
+
+
+@pytest.fixture
+def front_door():
+    """``sys.path`` as INTEGRATION.md prescribes: compat/ first; the imported shims are dropped again afterwards."""
+    saved = {k: sys.modules.pop(k) for k in ("models", "model_wrapper", "lossfunction", "data", "misc") if k in sys.modules}
+    sys.path.insert(0, COMPAT)
+    try:
+        yield
+    finally:
+        sys.path.remove(COMPAT)
+        for k in ("models", "model_wrapper", "lossfunction"):
+            sys.modules.pop(k, None)
+        sys.modules.update(saved)
+        ops.set_compute_dtype(torch.float32)
+
+
+def test_compat_does_not_shadow_callers_data_and_misc(front_door):
+    assert not os.path.exists(os.path.join(COMPAT, "data.py")) and not os.path.exists(os.path.join(COMPAT, "misc.py"))
+    models = importlib.import_module("models")
+    mw = importlib.import_module("model_wrapper")
+    assert models.__file__.startswith(COMPAT) and mw.__file__.startswith(COMPAT)
+    assert models.Generator.__module__.startswith("semantic_pyramid_for_image_generation_amd")
+
+
+@pytest.mark.parametrize("tag,data_parallel", [("step_cf4_b4_seed1", True), ("step_cf1_b2_seed0", False)])
+def test_main_py_train_loop_matches_reference_metrics(front_door, tag, data_parallel, tmp_path, monkeypatch):
+    from models import Generator, Discriminator, VGG16          # main.py:52
+    from model_wrapper import ModelWrapper                       # main.py:53
+    import make_golden                                           # the committed generator of the goldens: same loader / batches
+    meta, arr = gu.load(tag)
+    ops.set_compute_dtype(torch.float32)                         # the mode that carries the 1e-3 contract
+    Gsd, Dsd, Vsd = gu.synth_states(meta)
+    # main.py:58-65
+    generator = Generator(channels_factor=float(meta["cf"])).cuda()          # argparse hands a float over (main.py:18)
+    discriminator = Discriminator(channel_factor=float(meta["cf"])).cuda()
+    vgg16 = VGG16()
+    vgg16.load_state_dict(Vsd)
+    generator_optimizer = torch.optim.Adam(generator.parameters(), lr=meta["lr"])
+    discriminator_optimizer = torch.optim.Adam(discriminator.parameters(), lr=meta["lr"])
+    # main.py:68-73 (checkpoint path: the synthesized state plays the checkpoint)
+    generator.load_state_dict(Gsd)
+    discriminator.load_state_dict(Dsd)
+    training_dataset = make_golden.TwoBatchLoader(make_golden.golden_batches(meta["batch_size"], meta["seed"]), meta["batch_size"])
+    if data_parallel:                                            # main.py:91-94
+        generator = nn.DataParallel(generator)
+        discriminator = nn.DataParallel(discriminator)
+        vgg16 = nn.DataParallel(vgg16)
+    model_wrapper = ModelWrapper(generator=generator, discriminator=discriminator, vgg16=vgg16,          # main.py:97-103
+                                 training_dataset=training_dataset, validation_dataset=None,
+                                 generator_optimizer=generator_optimizer, discriminator_optimizer=discriminator_optimizer,
+                                 save_data_path=str(tmp_path))
+    # the loop draws its latents on the device (model_wrapper.py:147,168); the goldens recorded the reference's draws
+    noise = [torch.from_numpy(a) for a in arr["noise"]]
+    real_randn = torch.randn
+
+    def randn_replay(*a, **k):
+        shape = a[0] if len(a) == 1 and isinstance(a[0], (tuple, list, torch.Size)) else a
+        if tuple(shape) == (meta["batch_size"], 128) and noise:
+            return noise.pop(0).to(k.get("device", "cpu"))
+        return real_randn(*a, **k)
+    monkeypatch.setattr(torch, "randn", randn_replay)
+    monkeypatch.setattr(torch, "save", lambda *a, **k: None)     # skip the epoch checkpoint, as make_golden.py does
+    model_wrapper.train(epochs=1, device="cuda")                 # main.py:107
+    assert not noise, "the loop must draw exactly two latent batches per iteration"
+    log = model_wrapper.logger.metrics
+    for name in LOSS_NAMES:
+        got = [float(v) for v in log[name]]
+        assert len(got) == 2, (name, got)
+        for it in range(2):
+            assert got[it] == pytest.approx(meta[name][it], rel=1e-3, abs=1e-6), (name, it, got, meta[name])
+    assert [int(v) for v in log["iterations"]] == [meta["batch_size"], 2 * meta["batch_size"]]
+    assert [int(v) for v in log["epoch"]] == [0, 0]
+    G = model_wrapper.generator
+    gu.check_checksums({k: v.detach().cpu() for k, v in G.state_dict().items()}, meta["final_checksums_G"], rtol=1e-3, what="G final",
+                       noise_keys=gu.zero_gradient_keys(meta, arr, "grads_g"), noise_atol=2 * meta["lr"])

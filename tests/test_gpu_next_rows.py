@@ -1,0 +1,134 @@
+"""SURVEY.md section 8(f) rows on the device: f1 on-device mask generation feeding a training step, f3 checkpoint round trip
+through a running GPU job (reference layout, model_wrapper.py:215-223 / main.py:61,68-73) incl. the
+``VGG16(path_to_pre_trained_model)`` constructor branch (models.py:163-181)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import golden_util as gu  # noqa: E402
+import semantic_pyramid_for_image_generation_amd as sp  # noqa: E402
+from semantic_pyramid_for_image_generation_amd import models, ops, params, synthetic  # noqa: E402
+
+LOSS_NAMES = ("loss_discriminator_real", "loss_discriminator_fake", "loss_generator",
+              "loss_generator_semantic_reconstruction", "loss_generator_diversity")
+
+
+@pytest.fixture(autouse=True)
+def _dtype_reset():
+    yield
+    ops.set_compute_dtype(torch.float32)
+
+
+def build(cf, seed):
+    meta = {"cf": cf, "seed": seed}
+    Gsd, Dsd, Vsd = gu.synth_states(meta)
+    G = sp.Generator(channels_factor=cf); D = sp.Discriminator(channel_factor=cf); V = sp.VGG16()
+    G.load_state_dict(Gsd); D.load_state_dict(Dsd); V.load_state_dict(Vsd)
+    return G.cuda(), D.cuda(), V.cuda().eval()
+
+
+def wrapper(G, D, V, lr=1e-4):
+    og, od = sp.optim.Adam(G.parameters(), lr=lr), sp.optim.Adam(D.parameters(), lr=lr)
+    mw = sp.ModelWrapper(generator=G, discriminator=D, vgg16=V, training_dataset=None, validation_dataset=None,
+                         generator_optimizer=og, discriminator_optimizer=od, save_data_path=None)
+    G.train(); D.train()
+    return mw, og, od
+
+
+def test_device_mask_generation_contract_and_step():
+    """Row f1: synthetic.training_masks_device() on the GPU keeps the a15 contract (exact 0/1 values, one open stage per
+    sample counted from the deep end, finer levels = nearest-neighbour copies of one rectangle map, deeper levels zero) and
+    its output drives a training step directly - no host round trip."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    masks = synthetic.training_masks_device(256, "cuda", g)
+    shapes = [(1, 128, 128), (1, 64, 64), (1, 32, 32), (1, 16, 16), (1, 8, 8), (4096,), (365,)]
+    assert all(m.is_cuda and m.dtype == torch.float32 for m in masks)
+    assert [tuple(t.shape[1:]) for t in masks] == shapes
+    host = [m.cpu() for m in masks]
+    n_spatial = 0
+    for b in range(256):
+        m = [t[b] for t in host]
+        for t in m:
+            assert set(t.unique().tolist()) <= {0.0, 1.0}
+        full = [i for i, t in enumerate(m) if bool((t == 1).all()) and all(float(m[j].max()) == 0.0 for j in range(i + 1, 7))]
+        assert len(full) >= 1
+        i = max(full)
+        finer = [j for j in range(i) if float(m[j].max()) > 0]
+        if finer:
+            n_spatial += 1
+            assert finer == list(range(i)) and i - 1 <= 4
+            for j in range(i - 1):
+                assert torch.equal(m[j], F.interpolate(m[i - 1][None], size=m[j].shape[1:], mode="nearest")[0])
+    assert 0.05 < n_spatial / 256 < 0.35
+    ops.set_compute_dtype(torch.bfloat16)
+    G, D, V = build(4, 5)
+    mw, _, _ = wrapper(G, D, V)
+    images, labels, _ = synthetic.synthetic_batch(8, 2)
+    out = mw.train_step(images.cuda(), labels.cuda(), synthetic.training_masks_device(8, "cuda", g))
+    for n in LOSS_NAMES:
+        assert np.isfinite(float(out[n])), n
+
+
+def test_checkpoint_round_trip_on_the_device(tmp_path):
+    """Row f3: iteration 1, checkpoint in the reference's layout, fresh objects restored from the file, iteration 2 - against the
+    uninterrupted run.  fp32 mode reduces in a fixed order, so the two runs must agree bit for bit."""
+    ops.set_compute_dtype(torch.float32)
+    batches = gu.golden_batches(4, 1)
+    noise = torch.randn(4, 4, 128, generator=torch.Generator().manual_seed(2)).cuda()
+
+    def step(mw, it):
+        images, labels, masks = batches[it]
+        return mw.train_step(images.cuda(), labels.cuda(), [m.cuda() for m in masks], noise_d=noise[2 * it], noise_g=noise[2 * it + 1])
+
+    G, D, V = build(4, 1)
+    mw, og, od = wrapper(G, D, V)
+    step(mw, 0)
+    path = os.path.join(tmp_path, "checkpoint_000.pt")
+    torch.save({"generator": G.state_dict(), "discriminator": D.state_dict(),               # model_wrapper.py:215-223
+                "generator_optimizer": og.state_dict(), "discriminator_optimizer": od.state_dict()}, path)
+    ref = step(mw, 1)
+    ref_state = {k: v.detach().clone() for k, v in G.state_dict().items()}
+
+    ck = torch.load(path, map_location="cpu")                                                # main.py:68-73
+    assert all(any(k.endswith(s) for k in ck["generator"]) for s in ("weight_orig", "weight_u", "weight_v"))
+    G2 = sp.Generator(channels_factor=4).cuda(); D2 = sp.Discriminator(channel_factor=4).cuda()
+    og2 = torch.optim.Adam(G2.parameters(), lr=1e-4); od2 = torch.optim.Adam(D2.parameters(), lr=1e-4)   # plain torch optimizers, as main.py:64-65
+    G2.load_state_dict(ck["generator"]); D2.load_state_dict(ck["discriminator"])
+    og2.load_state_dict(ck["generator_optimizer"]); od2.load_state_dict(ck["discriminator_optimizer"])
+    mw2 = sp.ModelWrapper(generator=G2, discriminator=D2, vgg16=V, training_dataset=None, validation_dataset=None,
+                          generator_optimizer=og2, discriminator_optimizer=od2, save_data_path=None)
+    G2.train(); D2.train()
+    got = step(mw2, 1)
+    for n in LOSS_NAMES:
+        assert float(got[n]) == float(ref[n]), n
+    assert torch.equal(got["images_fake"], ref["images_fake"])
+    # torch's own Adam arithmetic (foreach kernels) vs sp_adam_multi: same operation order, compared to fp32 rounding
+    for k, v in G2.state_dict().items():
+        assert torch.allclose(v.float(), ref_state[k].float(), rtol=1e-6, atol=1e-8), k
+
+
+def test_vgg16_constructor_loads_a_pretrained_file(tmp_path):
+    """models.py:163-181: ``VGG16(path_to_pre_trained_model=...)`` unpickles a whole torchvision-style model and adopts its
+    parameters (main.py:61 instead loads a state_dict into ``VGG16()``: both routes must give the same pyramid)."""
+    topo = models._VGG16Topology(num_classes=365)
+    sd = params.synth_state_dict({"vgg16." + k: v for k, v in topo.state_dict().items()}, 9)
+    topo.load_state_dict({k[len("vgg16."):]: v for k, v in sd.items()})
+    path = os.path.join(tmp_path, "vgg_places_365_fine_tuned.pt")
+    torch.save(topo, path)
+    a = sp.VGG16(path_to_pre_trained_model=path).cuda().eval()
+    b = sp.VGG16()
+    b.load_state_dict(sd)
+    b = b.cuda().eval()
+    assert list(a.state_dict().keys()) == list(b.state_dict().keys())
+    ops.set_compute_dtype(torch.float32)
+    images, _, _ = synthetic.synthetic_batch(2, 4)
+    with torch.no_grad():
+        fa, fb = a(images.cuda()), b(images.cuda())
+    assert len(fa) == 7
+    for x, y in zip(fa, fb):
+        assert torch.equal(x, y)

@@ -109,6 +109,21 @@ def test_sn_conv_forward_backward(case, dtype):
     close(m.bias.grad, S["c.bias"].grad, tol * 2, "dbias")
 
 
+# The launches that dominate the benchmark step (bench.py: channel_factor 1, batch 20 per GPU), at their real sizes
+REAL_SHAPE_CASES = [(256, 256, 3, 20, 64, 64), (512, 512, 3, 20, 32, 32), (64, 64, 3, 20, 256, 256), (512, 512, 3, 20, 16, 16),
+                    (128, 128, 3, 20, 128, 128), (512, 512, 3, 20, 8, 8), (768, 768, 3, 20, 4, 4)]
+
+
+@pytest.mark.parametrize("case", REAL_SHAPE_CASES)
+def test_sn_conv_real_benchmark_shapes_bf16(case):
+    """Forward, input gradient and weight gradient of the fat 3x3 layers at the benchmark's own shapes (B = 20, bf16: the tall
+    LDS-DMA kernels with hundreds of work items per launch, the row-walker weight gradient with 512 partial slabs, the
+    split-K small-spatial kernels) against the oracle."""
+    import os
+    torch.set_num_threads(min(32, len(os.sched_getaffinity(0))))
+    test_sn_conv_forward_backward(case, torch.bfloat16)
+
+
 TALL_CASES = [(64, 128, 3, 1, 32, 32), (96, 160, 3, 2, 32, 64), (40, 192, 3, 1, 16, 32), (520, 128, 3, 1, 16, 32),
               (128, 136, 3, 3, 48, 96),
               # 64-channel-output variant (a wave = 64 co x 2 rows), incl. the 3->8 padded first layer

@@ -14,6 +14,10 @@ from oracle import sempyr_oracle as O  # noqa: E402
 import semantic_pyramid_for_image_generation_amd as sp  # noqa: E402
 from semantic_pyramid_for_image_generation_amd import ops, params  # noqa: E402
 
+# per-parameter gradient norms / samples vs the reference (the oracle itself - torch CPU at another thread count - differs
+# from the goldens by up to 2e-3 on these)
+GRAD_NORM_RTOL = 5e-3
+
 LOSS_NAMES = ("loss_discriminator_real", "loss_discriminator_fake", "loss_generator",
               "loss_generator_semantic_reconstruction", "loss_generator_diversity")
 
@@ -70,19 +74,19 @@ def test_train_step_fp32_matches_reference_golden(tag):
             assert float(out[n]) == pytest.approx(meta[n][it], rel=1e-3, abs=1e-6), (n, it)
         fake = out["images_fake"].float().cpu().contiguous().flatten()[pix_idx].numpy()
         ref = arr["fake_samples"][2 * it + 1]
-        # iteration 0 is pure forward parity (measured 8e-6).  From iteration 1 on the pixels have been through an Adam step,
-        # whose first update is lr * g / (|g| + eps): a parameter whose gradient is of the order of eps = 1e-8 turns a 1e-4
-        # relative gradient difference (fp32 summation order; our split-K weight gradients use fp32 atomics, so the order also
-        # varies from run to run) into a visible update difference.  40 repeated runs (scratch/stress_golden.py) give
-        # 7.0e-4 .. 1.06e-3 at iteration 1, so 1e-3 would be a coin flip there; the bound for post-update iterations is 2e-3.
-        pix_tol = 1e-3 if it == 0 else 2e-3
-        assert np.abs(fake - ref).max() <= pix_tol * np.abs(ref).max(), ("pixels", it, float(np.abs(fake - ref).max() / np.abs(ref).max()))
+        # north_star bound: 1e-3 on generator pixels, every iteration.  Iteration 0 is pure forward parity (measured 8e-6).  From
+        # iteration 1 on the pixels have been through an Adam step, whose first update is lr * g / (|g| + eps): parameters whose
+        # gradient is of the order of eps = 1e-8 turn a 1e-4 relative gradient difference into a visible update difference.
+        # Round 1 merged the split-K weight-gradient partials (and W^T u of the power iteration) with fp32 atomics: 40 repeated
+        # runs gave 7.0e-4 .. 1.06e-3 at iteration 1 and the bound had to be restated to 2e-3.  The fp32 mode now reduces in a
+        # fixed order (fp64 slab sums), so the result is a constant, not a distribution (test_fp32_step_is_bit_reproducible).
+        pix_tol = 1e-3
         for key, gkey in (("grads_d", "d"), ("grads_g", "g")):
             norms = np.array([float(g.double().norm()) for g in out["grads"][gkey]])
             refn = arr[key + "_norms"][it]
-            assert np.all(np.abs(norms - refn) <= 1e-2 * refn + 1e-5 * refn.max()), (key, it, np.abs(norms - refn).max())
+            assert np.all(np.abs(norms - refn) <= GRAD_NORM_RTOL * refn + 1e-5 * refn.max()), (key, it, float((np.abs(norms - refn) / (refn + 1e-5 * refn.max())).max()))
             s, rs = gu.grad_samples(out["grads"][gkey]), arr[key + "_samples"][it]
-            assert np.abs(s - rs).max() <= 1e-2 * np.abs(rs).max(), (key, it)
+            assert np.abs(s - rs).max() <= GRAD_NORM_RTOL * np.abs(rs).max(), (key, it, float(np.abs(s - rs).max() / np.abs(rs).max()))
     steps_lr = 2 * meta["lr"]
     gu.check_checksums({k: v.detach().cpu() for k, v in G.state_dict().items()}, meta["final_checksums_G"], rtol=1e-3, what="G final",
                        noise_keys=gu.zero_gradient_keys(meta, arr, "grads_g"), noise_atol=steps_lr)
@@ -90,8 +94,33 @@ def test_train_step_fp32_matches_reference_golden(tag):
                        noise_keys=gu.zero_gradient_keys(meta, arr, "grads_d"), noise_atol=steps_lr)
 
 
-def test_train_step_bf16_restated_tolerance():
-    meta, arr, G, D, outs = run_steps("step_cf4_b4_seed1", torch.bfloat16)
+def test_fp32_step_is_bit_reproducible():
+    """The parity mode reduces in a fixed order everywhere (SP_TUNE_DETERMINISTIC defaults to on for fp32 storage): two runs of
+    the two-iteration step from the same state give bit-identical losses, pixels, gradients and final parameters."""
+    runs = []
+    for _ in range(2):
+        meta, arr, G, D, outs = run_steps("step_cf4_b4_seed1", torch.float32)
+        runs.append((outs, {k: v.detach().clone() for k, v in G.state_dict().items()}, {k: v.detach().clone() for k, v in D.state_dict().items()}))
+    (o0, g0, d0), (o1, g1, d1) = runs
+    for it in range(len(o0)):
+        for n in LOSS_NAMES:
+            assert float(o0[it][n]) == float(o1[it][n]), (n, it)
+        assert torch.equal(o0[it]["images_fake"], o1[it]["images_fake"]), ("pixels", it)
+        for key in ("d", "g"):
+            for a, b in zip(o0[it]["grads"][key], o1[it]["grads"][key]):
+                assert torch.equal(a, b), (key, it)
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+    for k in d0:
+        assert torch.equal(d0[k], d1[k]), k
+
+
+@pytest.mark.parametrize("tag", ["step_cf1_b2_seed0", "step_cf4_b4_seed1"])
+def test_train_step_bf16_restated_tolerance(tag):
+    """The THROUGHPUT mode (bf16 storage + bf16 MFMA, fp32 accumulate: what bench.py times) against the reference goldens, incl.
+    the benchmark's own channel_factor = 1.  Restated tolerance (bf16 has 8 mantissa bits; the reference is fp32 end to end):
+    losses 5e-2 relative, pixels 8e-2 of the (-1, 1) range at the worst sample and 2e-2 rms."""
+    meta, arr, G, D, outs = run_steps(tag, torch.bfloat16)
     pix_idx = gu.fixed_indices(meta["batch_size"] * 3 * 256 * 256, gu.N_PIX, 0)
     for it, out in enumerate(outs):
         for n in LOSS_NAMES:
