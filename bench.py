@@ -2,15 +2,27 @@
 """Benchmark of the hot path: images/sec of one full discriminator + generator training step
 (/root/reference/model_wrapper.py:131-190 semantics incl. both Adam steps) on synthetic 256x256 batches.
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: the script starts its own N ranks (one process per GPU, spawned BEFORE the parent touches the GPU; the parent only
+relays rank 0's JSON line) unless it already runs under ``python -m torch.distributed.run`` (RANK / WORLD_SIZE set), in which
+case it is a rank.  Rendezvous is 127.0.0.1.
 
 Workload (BASELINE.json metric): channel_factor=1, batch 20 per GPU, bf16 storage / bf16 MFMA / fp32 accumulate,
 synthetic images / labels / masks with the reference's input contract, random-init G and D, kaiming-init frozen
-VGG-16, Adam lr 1e-5.  Prints ONE JSON line on rank 0.
+VGG-16, Adam lr 1e-5.  Prints ONE JSON line on rank 0.  Beside the headline it carries (N = 1 only):
+  roofline.families   conv forward / input-gradient / weight-gradient: ms per step and TFLOP/s of every launch, timed with events
+                      on the launch stream in two eager steps; roofline.frac is the FLOP-weighted fraction over ALL of them
+  parity_mode         the same step in the fp32 mode (exact-fp32 MFMA, ordered reductions) - the mode that carries the
+                      1e-3 parity contract (tests/test_gpu_step.py)
+  batch32             BASELINE.json config 2 (one GPU, bf16, batch 32)
+  cpu_baseline        the CPU oracle (torch fp32 on the host cores) at batch 2 and batch 20, with the CPU model
 """
 import argparse
+import gc
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,31 +35,75 @@ sys.path.insert(0, ROOT)
 # (SURVEY.md section 8d): D-step 210.40 + G-step 199.34 GFLOP at channel_factor = 1.
 GFLOP_PER_IMAGE = {1: 409.74, 2: 197.75, 0.5: 1239.60}
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}      # dense MFMA peaks, MI355X_MICROARCH.md
+DOMINANT_KERNEL = "conv3x3_tall_kernel<bf16,2,8> (sp_conv2d_igemm, 3x3, Cout>64, 128 co x 8x32 px tiles)"
+DOMINANT_KERNEL_SYMBOL = "conv3x3_tall_kernel<bf16, 2, 8>"
+TRAFFIC_FILES = ("round2_hbm_traffic_per_kernel.json", "round1_hbm_traffic_per_kernel.json")
 
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--steps", type=int, default=50)
+    p.add_argument("--warmup", type=int, default=10)
     p.add_argument("--batch", type=int, default=20, help="batch per GPU")
     p.add_argument("--channel-factor", type=float, default=1)
     p.add_argument("--dtype", choices=("bf16", "f32"), default="bf16")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-probe", action="store_true")
+    p.add_argument("--no-sub-records", action="store_true", help="skip the fp32 parity-mode and batch-32 sub-records")
+    p.add_argument("--device-masks", action="store_true",
+                   help="draw a fresh batch of training masks ON THE DEVICE every step (synthetic.training_masks_device, SURVEY.md "
+                        "row f1) inside the timed region instead of reusing one resident batch")
     p.add_argument("--no-graphs", action="store_true",
-                   help="launch every kernel eagerly; default: the D phase and the G phase are replayed as two captured HIP "
-                        "graphs (ModelWrapper.capture_graphs): ~12 instead of ~22 ms of host time per step, which keeps a "
-                        "slow host from becoming the bottleneck (profiles/README.md)")
+                   help="launch every kernel eagerly; default: the D phase and the G phase are replayed as captured HIP "
+                        "graphs (ModelWrapper.capture_graphs), which keeps a slow host from becoming the bottleneck")
     return p.parse_args()
 
 
-def cpu_baseline(cf, seconds_budget=25.0):
-    """The CPU oracle (torch fp32, all host cores) on a bounded sample of the same workload: B=2 steps."""
+# ------------------------------------------------------------------------------------------------------------------
+# N > 1 without an outer launcher: spawn the ranks (the parent never initialises the GPU)
+# ------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(n: int) -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(globals()["__file__"])] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        p.wait()
+        rc = rc or p.returncode
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baseline (reported beside the GPU number, never the thing measured as `value`)
+# ------------------------------------------------------------------------------------------------------------------
+def cpu_model_name() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cf, seconds_budget=30.0):
+    """The CPU oracle (torch fp32) on a bounded sample of the same workload: batch 2 (the reference's own CPU-runnable case,
+    BASELINE.json configs[0]) and batch 20 (the benchmark's per-GPU batch), SURVEY.md section 8d."""
     from oracle import sempyr_oracle as O
     from semantic_pyramid_for_image_generation_amd import params, synthetic
-    # host cores actually available to this process, capped: beyond ~16 threads oneDNN's conv backward stops scaling
-    # (a 256-thread run on the GPU box took 410 s per batch-2 step)
+    # host cores available to this process; beyond ~16 threads oneDNN's conv backward stops scaling on the pool's hosts
+    # (a 256-thread run took 410 s per batch-2 step), so the thread count - reported as `cores` - is capped there
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     torch.set_num_threads(max(1, min(16, avail)))
     G = O.make_state(params.synth_state_dict(O.layout_template(O.generator_layout(cf)), 0))
@@ -55,48 +111,48 @@ def cpu_baseline(cf, seconds_budget=25.0):
     V = O.make_state(params.synth_state_dict(O.layout_template(O.vgg16_layout()), 2), frozen=True)
     og = torch.optim.Adam(O.trainable(G), lr=1e-5)
     od = torch.optim.Adam(O.trainable(D), lr=1e-5)
-    b = 2
-    images, labels, masks = synthetic.synthetic_batch(b, 0)
     g = torch.Generator().manual_seed(0)
-    times = []
     t_start = time.time()
-    for i in range(5):
-        nd, ng = torch.randn(b, 128, generator=g), torch.randn(b, 128, generator=g)
-        t0 = time.time()
-        O.train_step(G, D, V, og, od, images, labels, masks, nd, ng, skip_dead_d_wgrad=True)
-        times.append(time.time() - t0)
-        if time.time() - t_start > seconds_budget and len(times) >= 2:
-            break
-    steady = min(times[1:]) if len(times) > 1 else times[0]
-    return {"value": round(b / steady, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d steps of batch %d (cf=%g, 256x256, fp32) with oracle/sempyr_oracle.py, best steady step %.2fs"
-                      % (len(times), b, cf, steady)}
-
-
-DOMINANT_KERNEL_SYMBOL = "conv3x3_tall_kernel<bf16, 2, 8>"
+    results = {}
+    for b, max_steps, budget in ((2, 4, 0.3 * seconds_budget), (20, 2, seconds_budget)):
+        images, labels, masks = synthetic.synthetic_batch(b, 0)
+        times = []
+        for i in range(max_steps):
+            nd, ng = torch.randn(b, 128, generator=g), torch.randn(b, 128, generator=g)
+            t0 = time.time()
+            O.train_step(G, D, V, og, od, images, labels, masks, nd, ng, skip_dead_d_wgrad=True)
+            times.append(time.time() - t0)
+            if time.time() - t_start > budget and len(times) >= 2:
+                break
+        steady = min(times[1:]) if len(times) > 1 else times[0]
+        results[b] = (b / steady, len(times), steady)
+    return {"value": round(results[2][0], 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "cpu_model": cpu_model_name(), "host_cores_available": avail,
+            "batch20": {"value": round(results[20][0], 4), "unit": "images/sec", "steps": results[20][1], "step_s": round(results[20][2], 2)},
+            "sample": "oracle/sempyr_oracle.py (torch fp32 CPU restatement, pinned to the reference goldens), cf=%g, 256x256: %d steps of batch 2 "
+                      "(best steady step %.2fs) -> value; %d steps of batch 20 (best %.2fs) -> batch20"
+                      % (cf, results[2][1], results[2][2], results[20][1], results[20][2])}
 
 
 def recorded_traffic(symbol):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, collected in
     separate runs of this script and reduced by profiles/extract_traffic.py); PMC counters cannot be read from inside the
     process, so the committed summary is reported - None if it is missing."""
-    path = os.path.join(ROOT, "profiles", "round1_hbm_traffic_per_kernel.json")
-    try:
-        kernels = json.load(open(path))["kernels"]
-    except (OSError, ValueError, KeyError):
-        return None
-    for name, rec in kernels.items():
-        if symbol in name:
-            return rec["hbm_bytes_per_launch"]
+    for name in TRAFFIC_FILES:
+        try:
+            kernels = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
+        except (OSError, ValueError, KeyError):
+            continue
+        for kname, rec in kernels.items():
+            if symbol in kname:
+                return rec["hbm_bytes_per_launch"]
     return None
 
 
-def kernel_probe(step_fn, steps=2):
-    """Dominant kernel = conv3x3_tall_kernel<bf16,2,8> (3x3 convolutions with > 64 output channels on 128 co x 8x32 px tiles,
-    forward and input-gradient; largest share of a step in profiles/ - until file f the same launches ran on
-    conv3x3_halo_kernel<bf16,128,3>).  Every launch of it inside `steps` extra training steps is
-    bracketed by events on the launch stream: achieved = sum of algorithmic FLOPs (2*M*N*K of each launch, with the
-    16-byte padded Cin) / sum of durations."""
+def kernel_probe(step_fn, peak, steps=2):
+    """Every convolution launch (forward, input gradient, weight gradient - 99.6 % of the step's FLOPs) inside `steps` extra
+    EAGER training steps is bracketed by events on the launch stream; algorithmic FLOPs of a launch = 2*M*N*K.
+    Returns (families, dominant-kernel record, FLOP-weighted totals)."""
     from semantic_pyramid_for_image_generation_amd import ops
     ops.KERNEL_PROBE = []
     try:
@@ -106,102 +162,159 @@ def kernel_probe(step_fn, steps=2):
         rec = ops.KERNEL_PROBE
     finally:
         ops.KERNEL_PROBE = None
-    ms = sum(e0.elapsed_time(e1) for e0, e1, _ in rec)
-    flops = sum(f for _, _, f in rec)
-    n = max(len(rec), 1)
-    return {"kernel": "conv3x3_tall_kernel<bf16,2,8> (sp_conv2d_igemm, 3x3, Cout>64, 128 co x 8x32 px tiles)", "launches_per_step": len(rec) // steps,
-            "avg_launch_us": round(ms / n * 1e3, 2), "avg_algorithmic_gflop_per_launch": round(flops / n / 1e9, 3),
-            "tflops": round(flops / max(ms, 1e-9) / 1e9, 2), "ms_per_step": round(ms / steps, 3)}
+    fam = {}
+    dom_ms = dom_fl = 0.0
+    dom_n = 0
+    for e0, e1, fl, family, dominant in rec:
+        ms = e0.elapsed_time(e1)
+        f = fam.setdefault(family, [0.0, 0.0, 0])
+        f[0] += ms; f[1] += fl; f[2] += 1
+        if dominant:
+            dom_ms += ms; dom_fl += fl; dom_n += 1
+    families = {k: {"launches_per_step": v[2] // steps, "ms_per_step": round(v[0] / steps, 3), "gflop_per_step": round(v[1] / steps / 1e9, 1),
+                    "tflops": round(v[1] / max(v[0], 1e-9) / 1e9, 1), "frac": round(v[1] / max(v[0], 1e-9) / 1e9 / peak, 4)}
+                for k, v in sorted(fam.items())}
+    tot_ms = sum(v[0] for v in fam.values())
+    tot_fl = sum(v[1] for v in fam.values())
+    bwd_ms = sum(v[0] for k, v in fam.items() if k != "fwd")
+    bwd_fl = sum(v[1] for k, v in fam.items() if k != "fwd")
+    n = max(dom_n, 1)
+    dom = {"kernel": DOMINANT_KERNEL, "launches_per_step": dom_n // steps, "avg_launch_us": round(dom_ms / n * 1e3, 2),
+           "avg_algorithmic_gflop_per_launch": round(dom_fl / n / 1e9, 3), "tflops": round(dom_fl / max(dom_ms, 1e-9) / 1e9, 2),
+           "frac": round(dom_fl / max(dom_ms, 1e-9) / 1e9 / peak, 4), "ms_per_step": round(dom_ms / steps, 3)}
+    totals = {"tflops": round(tot_fl / max(tot_ms, 1e-9) / 1e9, 1), "ms_per_step": round(tot_ms / steps, 3),
+              "backward_tflops": round(bwd_fl / max(bwd_ms, 1e-9) / 1e9, 1)}
+    return families, dom, totals
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# one job = (channel factor, batch, dtype) on this rank
+# ------------------------------------------------------------------------------------------------------------------
+class Job:
+    def __init__(self, cf, batch, dtype_name, dev, world, rank, use_graphs=True, device_masks=False):
+        import semantic_pyramid_for_image_generation_amd as sp
+        from semantic_pyramid_for_image_generation_amd import distributed, ops, params, synthetic
+        self.batch, self.world = batch, world
+        dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
+        ops.set_compute_dtype(dtype)
+        torch.manual_seed(0)                                     # identical G/D init on every rank (default init, seed 0)
+        G = sp.Generator(channels_factor=cf).to(dev)
+        D = sp.Discriminator(channel_factor=cf).to(dev)
+        V = sp.VGG16()
+        V.load_state_dict(params.synth_state_dict(V.state_dict(), 2))      # kaiming-style weights: there is no pretrained file offline
+        V.to(dev).eval()
+        # torch.optim.Adam semantics / state (main.py:64-65), one multi-tensor launch per step (optim.py); SP_ADAM=torch keeps
+        # torch's own foreach kernels for A/B runs
+        adam = torch.optim.Adam if os.environ.get("SP_ADAM", "sempyr") == "torch" else sp.optim.Adam
+        opt_g = adam(G.parameters(), lr=1e-5)
+        opt_d = adam(D.parameters(), lr=1e-5)
+        reducer = distributed.GradientReducer() if world > 1 else None
+        self.mw = mw = sp.ModelWrapper(G, D, None, None, vgg16=V, generator_optimizer=opt_g, discriminator_optimizer=opt_d,
+                                       save_data_path=None, gradient_reducer=reducer)
+        G.train()
+        D.train()
+        images, labels, masks = synthetic.synthetic_batch(batch, 1234 + rank)
+        images, labels, masks = images.to(dev), labels.to(dev), [m.to(dev) for m in masks]
+        torch.manual_seed(100 + rank)                            # per-rank latent stream
+        mask_gen = torch.Generator(device=dev).manual_seed(7 + rank) if device_masks else None
+
+        def fresh_masks():
+            return synthetic.training_masks_device(batch, dev, mask_gen) if device_masks else masks
+
+        def eager_step():
+            return mw.train_step(images, labels, fresh_masks())
+        self.eager_step = eager_step
+        self.step = eager_step
+        self.launch_mode = "eager"
+        if use_graphs:
+            for _ in range(2):                                   # lazy state (packed VGG weights, kernel attributes) before the capture
+                eager_step()
+            try:
+                mw.capture_graphs(images, labels, masks)
+
+                def graphed_step():
+                    return mw.train_step_graphed(None, None, fresh_masks() if device_masks else None)   # images / labels stay resident
+                self.step = graphed_step
+                self.launch_mode = "hipgraph"
+            except Exception as exc:                             # capture is plumbing: fall back to eager launches, say so
+                print("bench.py: HIP-graph capture failed (%s: %s); running eagerly" % (type(exc).__name__, exc), file=sys.stderr)
+
+    def timed(self, steps, warmup):
+        import torch.distributed as dist
+        for _ in range(warmup):
+            self.step()
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = None
+        for _ in range(steps):
+            out = self.step()
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if self.world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t)
+        return elapsed, {k: float(v) for k, v in out.items() if k.startswith("loss")}
+
+    def close(self):
+        self.mw = self.step = self.eager_step = None
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
+def sub_record(cf, batch, dtype_name, dev, steps, warmup, use_graphs):
+    job = Job(cf, batch, dtype_name, dev, 1, 0, use_graphs)
+    elapsed, _ = job.timed(steps, warmup)
+    mode = job.launch_mode
+    job.close()
+    ips = batch * steps / elapsed
+    gf = GFLOP_PER_IMAGE.get(cf)
+    rec = {"dtype": dtype_name, "batch": batch, "value": round(ips, 2), "unit": "images/sec", "ms_per_step": round(elapsed / steps * 1e3, 3),
+           "steps": steps, "warmup": warmup, "launch": mode}
+    if gf:
+        rec["step_tflops"] = round(gf * ips / 1e3, 1)
+        rec["step_frac"] = round(gf * ips / 1e3 / PEAK_TFLOPS[dtype_name], 4)
+    return rec
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))             # nothing above touched the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs a torch.distributed.run launch with one rank per GPU" % args.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    import semantic_pyramid_for_image_generation_amd as sp
-    from semantic_pyramid_for_image_generation_amd import distributed, ops, params, synthetic
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    ops.set_compute_dtype(dtype)
     cf = args.channel_factor if args.channel_factor != int(args.channel_factor) else int(args.channel_factor)
-    torch.manual_seed(0)                                     # identical G/D init on every rank (default init, seed 0)
-    G = sp.Generator(channels_factor=cf).to(dev)
-    D = sp.Discriminator(channel_factor=cf).to(dev)
-    V = sp.VGG16()
-    V.load_state_dict(params.synth_state_dict(V.state_dict(), 2))      # kaiming-style weights: there is no pretrained file offline
-    V.to(dev).eval()
-    # torch.optim.Adam semantics / state (main.py:64-65), one multi-tensor launch per step (optim.py); SP_ADAM=torch keeps
-    # torch's own foreach kernels for A/B runs
-    adam = torch.optim.Adam if os.environ.get("SP_ADAM", "sempyr") == "torch" else sp.optim.Adam
-    opt_g = adam(G.parameters(), lr=1e-5)
-    opt_d = adam(D.parameters(), lr=1e-5)
-    reducer = distributed.GradientReducer() if world > 1 else None
-    mw = sp.ModelWrapper(G, D, None, None, vgg16=V, generator_optimizer=opt_g, discriminator_optimizer=opt_d,
-                         save_data_path=None, gradient_reducer=reducer)
-    G.train()
-    D.train()
-    images, labels, masks = synthetic.synthetic_batch(args.batch, 1234 + rank)
-    images, labels, masks = images.to(dev), labels.to(dev), [m.to(dev) for m in masks]
-    torch.manual_seed(100 + rank)                            # per-rank latent stream
-
-    def step():
-        return mw.train_step(images, labels, masks)
-
-    eager_step = step
-    launch_mode = "eager"
-    if not args.no_graphs:
-        for _ in range(2):                                   # lazy state (packed VGG weights, kernel attributes) before the capture
-            step()
-        try:
-            mw.capture_graphs(images, labels, masks)
-
-            def step():                                      # noqa: F811
-                return mw.train_step_graphed(images, labels, masks)
-            launch_mode = "hipgraph"
-        except Exception as exc:                             # capture is plumbing: fall back to eager launches, say so
-            print("bench.py: HIP-graph capture failed (%s: %s); running eagerly" % (type(exc).__name__, exc), file=sys.stderr)
-            step = eager_step
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
-    losses = {k: float(v) for k, v in out.items() if k.startswith("loss")}
+    job = Job(cf, args.batch, args.dtype, dev, world, rank, not args.no_graphs, args.device_masks)
+    elapsed, losses = job.timed(args.steps, args.warmup)
     # the probe runs extra training steps: with world > 1 they contain collectives, so EVERY rank takes them
-    kp = None
+    probe = None
+    peak = PEAK_TFLOPS[args.dtype]
     if not args.no_kernel_probe:
-        kp = kernel_probe(eager_step)                        # the probe brackets individual launches: eager steps
+        probe = kernel_probe(job.eager_step, peak)   # the probe brackets individual launches: eager steps
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
+    launch_mode = job.launch_mode
+    job.close()
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         ips = args.batch * world * args.steps / elapsed
         gf = GFLOP_PER_IMAGE.get(cf)
-        peak = PEAK_TFLOPS[args.dtype]
         achieved = (gf * ips / world / 1e3) if gf else None           # TFLOP/s per GPU, algorithmic
         line = {
             "metric": "images/sec full G+D train step, 256x256, bs/GPU=%d" % args.batch,
@@ -211,15 +324,31 @@ def main():
             "config": {"workload": "Semantic-Pyramid GAN D+G step, channel_factor=%g, 256x256x3, batch %d/GPU, Adam lr 1e-5, "
                                    "random-init G/D, kaiming-init frozen VGG-16" % (cf, args.batch),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                       "launch": launch_mode, "losses_last_step": losses},
+                       "launch": launch_mode, "masks": "fresh on-device batch per step" if args.device_masks else "one resident batch",
+                       "losses_last_step": losses},
             "roofline": {"bound": "mfma", "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None, "traffic": None,
+                         "basis": "achieved / frac: FLOP-weighted over every convolution launch of a step (forward + input gradient + weight "
+                                  "gradient, 2*M*N*K each, event-timed on the launch stream in eager steps); step_*: whole step incl. all "
+                                  "memory-bound kernels, %s algorithmic GFLOP per image (necessary work, SURVEY.md 8d) x images/s per GPU"
+                                  % (("%.2f" % gf) if gf else "n/a"),
                          "step_achieved": round(achieved, 2) if achieved else None,
-                         "step_frac": round(achieved / peak, 4) if achieved else None,
-                         "step_basis": "%.2f algorithmic GFLOP per image (necessary work, SURVEY.md 8d) x images/s per GPU" % gf if gf else None},
+                         "step_frac": round(achieved / peak, 4) if achieved else None},
         }
-        if kp is not None:
-            line["roofline"].update({"achieved": kp["tflops"], "frac": round(kp["tflops"] / peak, 4), "dominant_kernel": kp})
+        if probe is not None:
+            families, dom, totals = probe
+            line["roofline"].update({"achieved": totals["tflops"], "frac": round(totals["tflops"] / peak, 4),
+                                     "conv_ms_per_step_eager": totals["ms_per_step"], "backward_tflops": totals["backward_tflops"],
+                                     "backward_frac": round(totals["backward_tflops"] / peak, 4),
+                                     "families": families, "dominant_kernel": dom})
             line["roofline"]["traffic"] = recorded_traffic(DOMINANT_KERNEL_SYMBOL)
+        if world == 1 and not args.no_sub_records:
+            if args.dtype == "bf16":
+                line["parity_mode"] = sub_record(cf, args.batch, "f32", dev, 8, 3, not args.no_graphs)
+                line["parity_mode"]["note"] = ("fp32 storage, exact-fp32 MFMA, ordered (deterministic) reductions: the mode held to 1e-3 "
+                                               "on pixels and losses against the reference goldens")
+            if args.batch != 32:
+                line["batch32"] = sub_record(cf, 32, args.dtype, dev, 15, 5, not args.no_graphs)
+                line["batch32"]["note"] = "BASELINE.json config 2: one MI355X, batch 32"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cf)
         print(json.dumps(line), flush=True)

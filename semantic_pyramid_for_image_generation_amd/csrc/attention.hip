@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ q, 
         for (int qi = 0; qi < TQ; ++qi) P[qi * NK + j] = p[qi];
     }
     __syncthreads();
-    // dV[j][c] += sum_qi P[qi][j] dO[qi][c]: channel-major threads -> coalesced atomics
+    // dV[j][c] = sum_qi P[qi][j] dO[qi][c] of this query block: channel-major threads -> coalesced stores into its slab
     {
         const int cpar = DV < 256 ? DV : 256, jpar = 256 / cpar;
         const int c = tid % cpar, jph = tid / cpar;
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ q, 
                 float a = 0.f;
 #pragma unroll
                 for (int qi = 0; qi < TQ; ++qi) a += P[qi * NK + jj] * dcol[qi];
-                atomicAdd(dv + ((long)b * NK + jj) * DV + c, a);
+                dv[((long)blockIdx.x * gridDim.y + b) * NK * DV + (long)jj * DV + c] = a;      // slab of this query block
             }
         }
     }
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ q, 
             float a = 0.f;
 #pragma unroll
             for (int qi = 0; qi < TQ; ++qi) a += p[qi] * qs[qi * D + d];
-            atomicAdd(dk + ((long)b * NK + j) * D + d, a);
+            dk[((long)blockIdx.x * gridDim.y + b) * NK * D + (long)j * D + d] = a;
         }
     }
     __syncthreads();

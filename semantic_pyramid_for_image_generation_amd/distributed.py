@@ -1,14 +1,23 @@
 """One-process-per-GPU data parallelism for the training step (replaces nn.DataParallel, main.py:91-94).
 
-Every rank holds the full G, D and frozen VGG and a shard of the batch.  After each backward the gradients
-are averaged with bucketed all-reduces (RCCL over xGMI on the GPU node; gloo in the CPU tests) issued on a
-side stream so that the reduction of early buckets overlaps the packing of later ones and the optimizer of
-the other network.  Spectral-norm u/v evolve identically on all ranks (same weights -> same power iteration),
-BatchNorm statistics stay rank-local like DataParallel replicas.
+Every rank holds the full G, D and frozen VGG and a shard of the batch.  The gradients of a network live in ONE contiguous
+fp32 buffer (ops.SpectralNormBank.flat: the weight-gradient kernels and the batched spectral-norm backward write it, the
+parameters' .grad are views of it), so the reducer all-reduces ranges of that buffer IN PLACE - no flatten / unflatten copies -
+on a side stream (RCCL over xGMI on the GPU node; gloo in the CPU tests):
+
+  * eager launches: the bank's layer groups report as they finish inside the backward pass (`on_group_done`), and each group's
+    range goes to the side stream right then - the reduction of the late layers overlaps the backward of the early ones;
+  * captured graphs (bench.py default): the ranges are enqueued bucket by bucket as soon as the graph that holds the backward
+    has been launched;
+  * in both modes ModelWrapper joins the discriminator's reduction only after the generator forward of the G phase (which does
+    not read D), i.e. D's all-reduce hides under compute; G's reduction is joined before Adam(G).
+
+Spectral-norm u/v evolve identically on all ranks (same weights -> same power iteration), BatchNorm statistics stay rank-local
+like DataParallel replicas.
 """
 from __future__ import annotations
 
-from typing import List, Sequence
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -19,11 +28,54 @@ class GradientReducer:
         self.bucket_bytes = bucket_bytes
         self.group = process_group
         self._side = None
+        self._pending = 0
+        self.log: List[Tuple[int, int]] = []       # (start, stop) of every range reduced since the last join (tests)
 
     def world_size(self) -> int:
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
-    def _buckets(self, params: Sequence[torch.Tensor]) -> List[List[torch.Tensor]]:
+    # -------------------------------------------------------------------------------------------- flat, in place
+    def reduce_range(self, flat: torch.Tensor, start: int, stop: int) -> None:
+        """Average flat[start:stop] over all ranks, in place, asynchronously: the range must be final on the CURRENT stream at
+        the time of the call (GPU: an event orders the side stream behind it).  join() makes the results visible."""
+        ws = self.world_size()
+        if ws == 1 or stop <= start:
+            return
+        view = flat[start:stop]
+        self.log.append((start, stop))
+        if not flat.is_cuda:
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+            view.div_(ws)
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        ev = torch.cuda.Event()
+        ev.record()                                   # the producers of this range, enqueued so far on the current stream
+        self._side.wait_event(ev)
+        with torch.cuda.stream(self._side):
+            work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            work.wait()                               # side stream waits for the collective; the host does not
+            view.mul_(1.0 / ws)
+        self._pending += 1
+
+    def reduce_flat(self, flat: torch.Tensor, ranges: Sequence[Tuple[int, int]]) -> None:
+        for a, b in ranges:
+            self.reduce_range(flat, a, b)
+
+    def join(self) -> None:
+        """The current stream waits for every reduction enqueued so far."""
+        if self._pending:
+            torch.cuda.current_stream().wait_stream(self._side)      # `flat` is persistent: no allocator hand-over to record
+            self._pending = 0
+        self.log = []
+
+    # -------------------------------------------------------------------------------------------- per-parameter (fallback)
+    def reduce(self, params: Sequence[torch.Tensor]) -> None:
+        """Average ``p.grad`` of loose parameters (gradients that do not live in a bank's flat buffer: a network without
+        direct gradients, or a caller's own modules): bucketed flatten -> all-reduce -> scatter back, joined at once."""
+        ws = self.world_size()
+        if ws == 1:
+            return
         buckets, cur, size = [], [], 0
         for p in reversed(list(params)):          # reverse registration order ~ order in which backward finishes them
             if p.grad is None:
@@ -35,46 +87,15 @@ class GradientReducer:
                 cur, size = [], 0
         if cur:
             buckets.append(cur)
-        return buckets
-
-    def reduce(self, params: Sequence[torch.Tensor]) -> None:
-        """Average ``p.grad`` over all ranks, in place.  On the GPU every bucket is flattened, all-reduced, scaled and
-        scattered back on a side stream (RCCL orders its own stream against it); the main stream only joins at the end,
-        so the collective of one bucket overlaps the flatten/scatter copies of its neighbours and whatever the main
-        stream still has queued."""
-        ws = self.world_size()
-        if ws == 1:
-            return
-        buckets = self._buckets(params)
-        if not buckets:
-            return
-        on_gpu = buckets[0][0].grad.is_cuda
-        if on_gpu:
-            if self._side is None:
-                self._side = torch.cuda.Stream()
-            self._side.wait_stream(torch.cuda.current_stream())
-        ctx = torch.cuda.stream(self._side) if on_gpu else _Null()
-        with ctx:
-            pending = []
-            for bucket in buckets:
-                grads = [p.grad for p in bucket]
-                flat = torch._utils._flatten_dense_tensors(grads)
-                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                pending.append((bucket, grads, flat, work))
-            for bucket, grads, flat, work in pending:
-                work.wait()                      # GPU: makes the side stream wait for the collective; CPU: blocks
-                flat.div_(ws)
-                for g, r in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
-                    g.copy_(r)
-                if on_gpu:
-                    flat.record_stream(self._side)
-        if on_gpu:
-            torch.cuda.current_stream().wait_stream(self._side)
+        for bucket in buckets:
+            grads = [p.grad for p in bucket]
+            flat = torch._utils._flatten_dense_tensors(grads)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            flat.div_(ws)
+            for g, r in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
+                g.copy_(r)
 
 
-class _Null:
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *a):
-        return False
+def flat_of(module) -> Optional[torch.Tensor]:
+    bank = getattr(module, "_bank", None)
+    return bank.flat if bank is not None and bank.direct_grads else None

@@ -75,11 +75,70 @@ class ModelWrapper(object):
                      'generator_loss', 'discriminator_loss', 'diversity_loss', 'semantic_reconstruction_loss'):
             self.logger.hyperparameter[name] = str(getattr(self, name))
         self._d_params = [p for p in self.discriminator.parameters()]
-        # D runs twice per backward (real, fake): its gradients meet in the bank's flat buffers instead of 59 autograd sums
-        bank = getattr(self.discriminator, "_bank", None)
-        if bank is not None and os.environ.get("SP_DIRECT_GRADS", "1") == "1":
-            bank.direct_grads = True
+        self._g_params = [p for p in self.generator.parameters()]
+        # every gradient of a network lives in ONE flat fp32 buffer (ops.SpectralNormBank.flat; param.grad are views of it):
+        # D runs twice per backward (real, fake) and its gradients meet there instead of in 59 autograd sums, and the
+        # data-parallel reducer all-reduces ranges of the buffer in place.  SP_DIRECT_GRADS=0: plain autograd gradients.
+        self._banks = {}
+        if os.environ.get("SP_DIRECT_GRADS", "1") == "1":
+            for key, net, passes in (("d", self.discriminator, 2), ("g", self.generator, 1)):
+                bank = getattr(net, "_bank", None)
+                if bank is not None:
+                    bank.direct_grads = True
+                    bank.expected_passes = passes
+                    self._banks[key] = bank
+        self._graph_state = None
+        self._capturing = False
+        self._fired = set()
         self.iterations = 0
+
+    # ------------------------------------------------------------------------------------------
+    # data parallelism: flat, in-place, overlapped gradient reduction (distributed.GradientReducer)
+    # ------------------------------------------------------------------------------------------
+    def _arm_reducer(self, key: str) -> None:
+        """Before a backward pass launched eagerly: the bank's layer groups hand their flat range to the reducer the moment
+        their batched spectral-norm backward has been enqueued - while the rest of the backward pass still runs."""
+        bank = self._banks.get(key)
+        if bank is None:
+            return
+        bank.on_group_done = None
+        self._fired = set()
+        if self.gradient_reducer is not None and not self._capturing and self.gradient_reducer.world_size() > 1:
+            red = self.gradient_reducer
+
+            def done(start, stop, bank=bank):
+                self._fired.add((start, stop))
+                bucket = max(1, red.bucket_bytes // 4)
+                for a in range(start, stop, bucket):
+                    red.reduce_range(bank.flat, a, min(stop, a + bucket))
+            bank.on_group_done = done
+
+    def _finish_backward(self, key: str) -> None:
+        """After .backward(): non-SN gradients move into the flat buffer (inside the captured graph too)."""
+        bank = self._banks.get(key)
+        if bank is not None:
+            bank.on_group_done = None
+            bank.collect_extra()
+
+    def _start_reduce(self, key: str, params, eager: bool) -> None:
+        """Enqueues (side stream) whatever of the network's gradients has not been handed over by the group hooks."""
+        red = self.gradient_reducer
+        if red is None or red.world_size() == 1:
+            return
+        bank = self._banks.get(key)
+        if bank is None or bank.flat is None:
+            red.reduce(params)                        # loose gradients: flatten / all-reduce / scatter back
+            return
+        fired = self._fired if eager else set()
+        todo = []
+        for a, b in bank.flat_ranges(max(1, red.bucket_bytes // 4)):
+            if not any(fa <= a and b <= fb for fa, fb in fired):
+                todo.append((a, b))
+        red.reduce_flat(bank.flat, todo)
+
+    def _join_reduce(self) -> None:
+        if self.gradient_reducer is not None:
+            self.gradient_reducer.join()
 
     # ------------------------------------------------------------------------------------------
     def _d_phase(self, images_real, labels, labels_f, masks, noise_d):
@@ -95,17 +154,24 @@ class ModelWrapper(object):
         prediction_real = D(images_real, labels)
         prediction_fake = D(images_fake, labels)
         loss_d_real, loss_d_fake = self.discriminator_loss(prediction_real, prediction_fake)
+        self._arm_reducer("d")
         (loss_d_real + loss_d_fake).backward()
+        self._finish_backward("d")
         return features_real, loss_d_real, loss_d_fake
 
-    def _g_phase(self, images_real, labels, labels_f, masks, features_real, noise_g, w_rec, w_div):
-        """model_wrapper.py:165-188: forward passes and backward of the generator step (everything but Adam)."""
-        G, D, V = self.generator, self.discriminator, self.vgg16
+    def _g_forward(self, images_real, labels_f, masks, features_real, noise_g):
+        """model_wrapper.py:165-172: the generator forward of the G step.  It does not read the discriminator, so D's gradient
+        all-reduce and D's Adam step may still be in flight / pending while it runs (train_step)."""
+        G = self.generator
         G.zero_grad()
-        D.zero_grad()
         if noise_g is None:
             noise_g = torch.randn((images_real.shape[0], self.latent_dimensions), dtype=torch.float32, device=images_real.device)
-        images_fake = G(input=noise_g, features=features_real, masks=masks, class_id=labels_f)
+        return G(input=noise_g, features=features_real, masks=masks, class_id=labels_f), noise_g
+
+    def _g_rest(self, images_fake, noise_g, labels, masks, features_real, w_rec, w_div):
+        """model_wrapper.py:174-188: D(fake), the three generator losses, backward (everything but Adam)."""
+        D, V = self.discriminator, self.vgg16
+        D.zero_grad()
         for p in self._d_params:                               # dead D weight gradients are skipped
             p.requires_grad_(False)
         try:
@@ -114,25 +180,31 @@ class ModelWrapper(object):
             loss_div = w_div * self.diversity_loss(images_fake, noise_g)
             features_fake = V(images_fake)
             loss_rec = w_rec * self.semantic_reconstruction_loss(features_real, features_fake, masks)
+            self._arm_reducer("g")
             (loss_g + loss_rec + loss_div).backward()
+            self._finish_backward("g")
         finally:
             for p in self._d_params:
                 p.requires_grad_(True)
-        return loss_g, loss_rec, loss_div, images_fake
+        return loss_g, loss_rec, loss_div
 
     def train_step(self, images_real: torch.Tensor, labels: torch.Tensor, masks, w_rec: float = 0.1, w_div: float = 0.1,
                    noise_d: Optional[torch.Tensor] = None, noise_g: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """One iteration of model_wrapper.py:131-190 on tensors already on the device.  ``noise_d`` / ``noise_g``
         replace the two ``torch.randn`` draws (model_wrapper.py:147,168) for parity runs.  Returns the loss
-        scalars as device tensors (no host sync)."""
+        scalars as device tensors (no host sync).
+
+        Order of work (results identical to the reference's order): D phase; [D gradients -> side stream]; generator forward of
+        the G phase (independent of D); join; Adam(D); rest of the G phase; [G gradients -> side stream]; join; Adam(G)."""
         labels_f = labels.float()
         features_real, loss_d_real, loss_d_fake = self._d_phase(images_real, labels, labels_f, masks, noise_d)
-        if self.gradient_reducer is not None:
-            self.gradient_reducer.reduce(self._d_params)
+        self._start_reduce("d", self._d_params, eager=True)
+        images_fake, noise_g = self._g_forward(images_real, labels_f, masks, features_real, noise_g)
+        self._join_reduce()
         self.discriminator_optimizer.step()
-        loss_g, loss_rec, loss_div, images_fake = self._g_phase(images_real, labels, labels_f, masks, features_real, noise_g, w_rec, w_div)
-        if self.gradient_reducer is not None:
-            self.gradient_reducer.reduce([p for p in self.generator.parameters()])
+        loss_g, loss_rec, loss_div = self._g_rest(images_fake, noise_g, labels, masks, features_real, w_rec, w_div)
+        self._start_reduce("g", self._g_params, eager=True)
+        self._join_reduce()
         self.generator_optimizer.step()
         self.iterations += 1
         return {"loss_discriminator_real": loss_d_real.detach(), "loss_discriminator_fake": loss_d_fake.detach(),
@@ -141,13 +213,18 @@ class ModelWrapper(object):
 
     # ------------------------------------------------------------------------------------------
     def capture_graphs(self, images_real: torch.Tensor, labels: torch.Tensor, masks, w_rec: float = 0.1, w_div: float = 0.1) -> None:
-        """Records the two phases of train_step (all forward / backward kernels of the D step and of the G step, ~1000
-        launches) as two HIP graphs over static copies of the inputs; train_step_graphed() then costs two graph launches
-        plus the two optimizer steps, so the step time no longer depends on how fast the host can enqueue.  The shapes
+        """Records train_step as THREE HIP graphs over static copies of the inputs - the D phase, the generator forward of the G
+        phase, the rest of the G phase (~1000 kernel launches together); train_step_graphed() then costs three graph launches
+        plus the two optimizer steps, so the step time no longer depends on how fast the host can enqueue.  The cut after the
+        generator forward is where a multi-GPU run hides the discriminator's gradient all-reduce (distributed.py).  The shapes
         are static (fixed batch, 256x256); call after a few eager steps (lazy state: packed VGG weights, kernel
         attributes).  The two latent draws stay eager (two tiny launches into static buffers), so the device RNG is
         consumed exactly as in train_step()."""
         import gc
+        for bank in self._banks.values():
+            if bank.flat is None:
+                raise RuntimeError("capture_graphs(): run at least one eager train_step() first (the flat gradient buffers and the "
+                                   "packed VGG weights are allocated lazily and must not be born inside a graph's memory pool)")
         self.generator.zero_grad()
         self.discriminator.zero_grad()
         gc.collect()                       # no autograd nodes of earlier (eager-stream) iterations may survive into the capture
@@ -158,53 +235,63 @@ class ModelWrapper(object):
         zdim = (images_real.shape[0], self.latent_dimensions)
         st["noise_d"] = torch.zeros(zdim, dtype=torch.float32, device=images_real.device)
         st["noise_g"] = torch.zeros(zdim, dtype=torch.float32, device=images_real.device)
-        g_params = [p for p in self.generator.parameters()]
-        gd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gd):
-            labels_f = st["labels"].float()
-            feats, l_real, l_fake = self._d_phase(st["images"], st["labels"], labels_f, st["masks"], st["noise_d"])
-        st["d_grads"] = [p.grad for p in self._d_params]
-        gg = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gg, pool=gd.pool()):
-            labels_f = st["labels"].float()
-            l_g, l_rec, l_div, fake = self._g_phase(st["images"], st["labels"], labels_f, st["masks"], feats, st["noise_g"], w_rec, w_div)
-        st["g_grads"] = [p.grad for p in g_params]
-        st["g_params"], st["gd"], st["gg"], st["feats"] = g_params, gd, gg, feats
+        self._capturing = True
+        try:
+            gd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gd):
+                labels_f = st["labels"].float()
+                feats, l_real, l_fake = self._d_phase(st["images"], st["labels"], labels_f, st["masks"], st["noise_d"])
+            st["d_grads"] = [p.grad for p in self._d_params]
+            gf = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gf, pool=gd.pool()):
+                labels_f = st["labels"].float()
+                fake, _ = self._g_forward(st["images"], labels_f, st["masks"], feats, st["noise_g"])
+            gg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gg, pool=gd.pool()):
+                l_g, l_rec, l_div = self._g_rest(fake, st["noise_g"], st["labels"], st["masks"], feats, w_rec, w_div)
+            st["g_grads"] = [p.grad for p in self._g_params]
+        finally:
+            self._capturing = False
+        st["gd"], st["gf"], st["gg"], st["feats"] = gd, gf, gg, feats
         st["out"] = {"loss_discriminator_real": l_real.detach(), "loss_discriminator_fake": l_fake.detach(),
                      "loss_generator": l_g.detach(), "loss_generator_semantic_reconstruction": l_rec.detach().reshape(()),
                      "loss_generator_diversity": l_div.detach(), "images_fake": fake.detach()}
 
-    def train_step_graphed(self, images_real: torch.Tensor, labels: torch.Tensor, masks,
+    def train_step_graphed(self, images_real: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None, masks=None,
                            noise_d: Optional[torch.Tensor] = None, noise_g: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
-        """train_step() through the captured graphs (capture_graphs() first).  The returned tensors are the graphs' static
-        outputs: they are overwritten by the next call."""
+        """train_step() through the captured graphs (capture_graphs() first).  images / labels / masks: new batch to copy into
+        the graphs' static inputs, or None to reuse the resident one.  The returned tensors are the graphs' static outputs:
+        they are overwritten by the next call."""
         st = self._graph_state
         if noise_d is None:
             st["noise_d"].normal_()
         else:
             st["noise_d"].copy_(noise_d)
-        if images_real is not st["images"]:
+        if images_real is not None and images_real is not st["images"]:
             st["images"].copy_(images_real, non_blocking=True)
+        if labels is not None and labels is not st["labels"]:
             st["labels"].copy_(labels, non_blocking=True)
+        if masks is not None and masks is not st["masks"]:
             for dst, src in zip(st["masks"], masks):
                 dst.copy_(src, non_blocking=True)
         st["gd"].replay()
         for p, g in zip(self._d_params, st["d_grads"]):
             p.grad = g
-        if self.gradient_reducer is not None:
-            self.gradient_reducer.reduce(self._d_params)
-        self.discriminator_optimizer.step()
+        self._start_reduce("d", self._d_params, eager=False)
         if noise_g is None:
             st["noise_g"].normal_()
         else:
             st["noise_g"].copy_(noise_g)
+        st["gf"].replay()                                       # generator forward: overlaps the D gradient all-reduce
+        self._join_reduce()
+        self.discriminator_optimizer.step()
         st["gg"].replay()
-        for p, g in zip(st["g_params"], st["g_grads"]):
+        for p, g in zip(self._g_params, st["g_grads"]):
             p.grad = g
         for p in self._d_params:
             p.grad = None
-        if self.gradient_reducer is not None:
-            self.gradient_reducer.reduce(st["g_params"])
+        self._start_reduce("g", self._g_params, eager=False)
+        self._join_reduce()
         self.generator_optimizer.step()
         self.iterations += 1
         return st["out"]

@@ -133,6 +133,16 @@ def _collect_sn(root: nn.Module, no_dgrad=()):
     return specs
 
 
+def _non_sn_params(root: nn.Module):
+    """Parameters outside the spectral-normalised layers (conditional-BatchNorm embeddings, BatchNorm affine, attention gates):
+    the bank gives them slots at the tail of its flat gradient buffer (ops.SpectralNormBank.collect_extra)."""
+    sn = set()
+    for m in root.modules():
+        if isinstance(m, (SNConv2d, SNLinear, SNEmbedding)):
+            sn.update(id(p) for p in m.parameters(recurse=False))
+    return [p for p in root.parameters() if id(p) not in sn]
+
+
 # --------------------------------------------------------------------------------------------------
 # blocks
 # --------------------------------------------------------------------------------------------------
@@ -311,7 +321,7 @@ class Generator(nn.Module):
             nn.LeakyReLU(negative_slope=0.2),
             SNConv2d(ch(64), out_channels, 1))
         self.apply(init_weights)
-        self._bank = ops.SpectralNormBank(_collect_sn(self, no_dgrad=("masked_feature_mapping",)))
+        self._bank = ops.SpectralNormBank(_collect_sn(self, no_dgrad=("masked_feature_mapping",)), _non_sn_params(self))
         self._bn_list = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
         self._nbt_flat = None
 
@@ -391,7 +401,7 @@ class Discriminator(nn.Module):
         self.classification._sn_kind = "plain"          # consumed as an fp32 vector by the head kernel
         self.embedding = SNEmbedding(number_of_classes, 128)
         self.apply(init_weights)
-        self._bank = ops.SpectralNormBank(_collect_sn(self))
+        self._bank = ops.SpectralNormBank(_collect_sn(self), _non_sn_params(self))
 
     def forward(self, input: torch.Tensor, class_id: torch.Tensor) -> torch.Tensor:
         dt = ops.compute_dtype()
@@ -577,7 +587,7 @@ class _VGGPyramidFn(torch.autograd.Function):
                 # by the pool backward) or the image: fold that ReLU's derivative in via mask_src = the input itself
                 producer_is_conv = (not first) and ctx.trace[idx - 1][0] == "conv"
                 ops.conv_launch(g, pk["dgrad"].data_ptr(), None, dx, None, None, xin if producer_is_conv else None, 0.0, n, h, w,
-                                g.shape[1], pk["cin"], cin_p, 3, ACT_NONE, dtype)
+                                g.shape[1], pk["cin"], cin_p, 3, ACT_NONE, dtype, family="dgrad")
                 g = dx
         if g is None:
             return None, None, None

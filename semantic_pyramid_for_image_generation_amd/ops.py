@@ -167,48 +167,59 @@ def _zero1(device) -> torch.Tensor:
 
 
 class _SNBankFn(torch.autograd.Function):
-    """weight_orig of every layer -> one 1-element handle per layer.  The layer functions take their handle as an input,
-    so autograd runs this node's backward once ALL weight-gradient kernels of the pass have accumulated into the
-    arena; it then applies d(W/sigma)/dW to every layer in one batched call (torch.nn.utils.spectral_norm backward)."""
+    """weight_orig of the layers of ONE GROUP of a bank -> one 1-element handle per layer.  The layer functions take their
+    handle as an input, so autograd runs this node's backward once all weight-gradient kernels of the group have accumulated
+    into the arena; it then applies d(W/sigma)/dW to the group's layers in one batched call (torch.nn.utils.spectral_norm
+    backward).  A bank is cut into a few groups of consecutive layers (SpectralNormBank.groups): the groups near the output
+    finish early in the backward pass, which is what lets their gradient all-reduce start while the rest still computes."""
 
     @staticmethod
-    def forward(ctx, call: SNCall, *weights):
-        ctx.call = call
+    def forward(ctx, call: SNCall, group: int, *weights):
+        ctx.call, ctx.group = call, group
         dev = weights[0].device
         return tuple(torch.empty(1, dtype=torch.float32, device=dev) for _ in weights)
 
     @staticmethod
     def backward(ctx, *_):
-        call = ctx.call
+        call, g = ctx.call, ctx.group
         bank = call.bank
-        n = len(bank.specs)
+        lo, hi = bank.groups[g]
+        n = hi - lo
         if call.arena is None:
-            return (None,) * (n + 1)
+            return (None,) * (n + 2)
+        table = ctypes.c_void_p(bank.bwd_table_dev.data_ptr() + lo * ctypes.sizeof(L.SpSnBwdLayer))
+        dots = torch.empty(n * 512, dtype=torch.float32, device=call.arena.device)     # per-block partial <dW, W> sums
+        start, stop = bank.group_range[g]
         if bank.direct_grads:
-            # direct mode: the gradients of every pass of the window meet in the bank's persistent flat buffers and the
-            # parameters' .grad are views of them - autograd neither sums nor stores anything for these parameters
-            bank.enter_backward(call.arena.device)
-            prev = bank.flat_w if bank.win_count > 0 else None
-            dots = torch.empty(n * 512, dtype=torch.float32, device=call.arena.device)     # per-block partial <dW, W> sums
-            L.call("sp_sn_backward_batched", ptr(bank.bwd_table_dev), n, bank.max_elems, ptr(call.arena), ptr(call.scratch),
-                   ptr(bank.flat_w), ptr(prev), ptr(bank.flat_b), ptr(dots), stream())
-            bank.win_count += 1
-            bank.win_touched |= call.touched
-            bank.win_bias |= call.bias_touched
-            for i, (m, _, _) in enumerate(bank.specs):
-                if i in bank.win_touched and ctx.needs_input_grad[i + 1]:
+            # direct mode: the gradients of every pass of the window meet in the bank's persistent flat buffer and the
+            # parameters' .grad are views of it - autograd neither sums nor stores anything for these parameters
+            bank.enter_backward(call.arena.device, g)
+            prev = bank.flat if bank.group_count[g] > 0 else None
+            L.call("sp_sn_backward_batched", table, n, bank.max_elems, ptr(call.arena), ptr(call.scratch),
+                   ptr(bank.flat), ptr(prev), ptr(bank.flat), ptr(dots), stream())
+            bank.group_count[g] += 1
+            for i in range(lo, hi):
+                m = bank.specs[i][0]
+                if i in call.touched:
+                    bank.win_touched.add(i)
+                if i in call.bias_touched:
+                    bank.win_bias.add(i)
+                if i in bank.win_touched and ctx.needs_input_grad[i - lo + 2]:
                     m.weight_orig.grad = bank.w_views[i]
                 if i in bank.win_bias and m.bias.requires_grad:
                     m.bias.grad = bank.b_views[i]
-            return (None,) * (n + 1)
-        grads = torch.empty(bank.grad_floats, dtype=torch.float32, device=call.arena.device)
-        dots = torch.empty(n * 512, dtype=torch.float32, device=call.arena.device)
-        L.call("sp_sn_backward_batched", ptr(bank.bwd_table_dev), n, bank.max_elems, ptr(call.arena), ptr(call.scratch),
-               ptr(grads), None, None, ptr(dots), stream())
-        out = [None]
-        for i, (m, _, _) in enumerate(bank.specs):
-            if i in call.touched and ctx.needs_input_grad[i + 1]:
-                off = bank.grad_offs[i]
+            if bank.on_group_done is not None and bank.group_count[g] == bank.expected_passes:
+                bank.on_group_done(start, stop)
+            return (None,) * (n + 2)
+        grads = torch.empty(stop - start, dtype=torch.float32, device=call.arena.device)
+        # the table's offsets address the bank-wide flat layout: hand the kernel the base this group's slice would have there
+        L.call("sp_sn_backward_batched", table, n, bank.max_elems, ptr(call.arena), ptr(call.scratch),
+               ctypes.c_void_p(grads.data_ptr() - 4 * start), None, None, ptr(dots), stream())
+        out = [None, None]
+        for i in range(lo, hi):
+            m = bank.specs[i][0]
+            if i in call.touched and ctx.needs_input_grad[i - lo + 2]:
+                off = bank.grad_offs[i] - start
                 out.append(grads[off:off + m.weight_orig.numel()].view(m.weight_orig.shape))
             else:
                 out.append(None)
@@ -219,39 +230,69 @@ class SpectralNormBank:
     """specs: list of (module, kind, need_dgrad); module has weight_orig / weight_u / weight_v.
     kind: 'conv' (O,I,kh,kw), 'linear' (O,K), 'plain' (fp32 copy, e.g. the SN embedding)."""
 
-    def __init__(self, specs: Sequence):
+    N_GROUPS = 4
+
+    def __init__(self, specs: Sequence, extra_params: Sequence = ()):
         self.specs = list(specs)
         for i, (m, _, _) in enumerate(self.specs):
             m._sn_bank, m._sn_slot = self, i
         self.current: Optional[SNCall] = None
         self.handles = None
         self._key = None
-        # direct_grads (opt-in, ModelWrapper sets it on the discriminator): a network that runs SEVERAL forward passes per
-        # backward (D(real) and D(fake), model_wrapper.py:150-160) gets its weight_orig / bias gradients accumulated by the
-        # kernels into persistent flat buffers; param.grad are views of them.  A window of passes ends when the
-        # parameters' .grad are reset (zero_grad): see enter_backward().  torch.autograd.grad() does not see these
-        # gradients - leave the flag off for anything but .backward() training steps.
+        # direct_grads (opt-in, ModelWrapper sets it): the weight_orig / bias gradients are accumulated by the kernels into ONE
+        # persistent flat fp32 buffer (`flat`) and param.grad are views of it.  A network that runs SEVERAL forward passes per
+        # backward (D(real) and D(fake), model_wrapper.py:150-160) gets them summed there, without per-parameter autograd
+        # additions; and the data-parallel reducer all-reduces contiguous ranges of the buffer in place.  A window of passes
+        # ends when the parameters' .grad are reset (zero_grad): see enter_backward().  torch.autograd.grad() does not see
+        # these gradients - leave the flag off for anything but .backward() training steps.
+        # extra_params: the network's parameters that are NOT spectral-normalised layers (class embeddings of the conditional
+        # BatchNorm layers, the attention gate ...): collect_extra() moves their autograd gradients into the tail of `flat`.
         self.direct_grads = False
-        self.flat_w = self.flat_b = None
-        self.win_count, self.win_touched, self.win_bias = 0, set(), set()
+        self.extra_params = list(extra_params)
+        self.flat = None
+        self.group_count: List[int] = []
+        self.win_touched, self.win_bias = set(), set()
+        self.expected_passes = 1               # passes per window after which on_group_done fires (ModelWrapper: 2 for D, 1 for G)
+        self.on_group_done = None              # callable(start, stop): floats [start, stop) of `flat` are final (eager launches only)
 
-    def enter_backward(self, device) -> None:
-        """Start of a pass's batched backward (direct mode).  The window continues iff the gradients assigned by the
+    def _alloc_flat(self, device) -> None:
+        self.flat = torch.zeros(self.flat_floats, dtype=torch.float32, device=device)
+        self.w_views = [self.flat[o:o + m.weight_orig.numel()].view(m.weight_orig.shape)
+                        for o, (m, _, _) in zip(self.grad_offs, self.specs)]
+        self.b_views = [self.flat[o:o + m.weight_orig.shape[0]] for o, (m, _, _) in zip(self.bias_offs, self.specs)]
+        self.extra_views = [self.flat[o:o + p.numel()].view(p.shape) for o, p in zip(self.extra_offs, self.extra_params)]
+        self.group_count = [0] * len(self.groups)
+        self.win_touched, self.win_bias = set(), set()
+
+    def enter_backward(self, device, group: int) -> None:
+        """Start of a group's batched backward (direct mode).  The window continues iff the gradients this group assigned in the
         previous pass are still in place (zero_grad(set_to_none=True) or a manual reset starts a new one)."""
-        if self.flat_w is None or self.flat_w.device != device:
-            self.flat_w = torch.empty(self.grad_floats, dtype=torch.float32, device=device)
-            self.flat_b = torch.empty(max(self.bias_floats, 1), dtype=torch.float32, device=device)
-            self.w_views = [self.flat_w[o:o + m.weight_orig.numel()].view(m.weight_orig.shape)
-                            for o, (m, _, _) in zip(self.grad_offs, self.specs)]
-            self.b_views = [self.flat_b[o:o + m.weight_orig.shape[0]] for o, (m, _, _) in zip(self.bias_offs, self.specs)]
-            self.win_count = 0
-        alive = self.win_count > 0
-        if alive:
-            probe = next(iter(self.win_touched), None)
-            g = self.specs[probe][0].weight_orig.grad if probe is not None else None
-            alive = g is not None and g.data_ptr() == self.w_views[probe].data_ptr()
-        if not alive:
-            self.win_count, self.win_touched, self.win_bias = 0, set(), set()
+        if self.flat is None or self.flat.device != device:
+            self._alloc_flat(device)
+        if self.group_count[group] > 0:
+            lo, hi = self.groups[group]
+            probe = next((i for i in range(lo, hi) if i in self.win_touched), None)
+            gr = self.specs[probe][0].weight_orig.grad if probe is not None else None
+            if gr is None or gr.data_ptr() != self.w_views[probe].data_ptr():
+                self.group_count[group] = 0
+                self.win_touched -= set(range(lo, hi))
+                self.win_bias -= set(range(lo, hi))
+
+    def collect_extra(self) -> None:
+        """After .backward() (direct mode): the autograd gradients of the non-SN parameters move into their slots at the tail
+        of `flat` (one multi-tensor copy) and .grad becomes the view, so that EVERY gradient of the network lives in `flat`."""
+        if not self.direct_grads or self.flat is None:
+            return
+        src, dst = [], []
+        for p, v in zip(self.extra_params, self.extra_views):
+            if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+                src.append(p.grad.reshape(v.shape) if p.grad.is_contiguous() else p.grad.contiguous())
+                dst.append(v)
+        if src:
+            torch._foreach_copy_(dst, src)
+            for p, v in zip(self.extra_params, self.extra_views):
+                if p.grad is not None:
+                    p.grad = v
 
     def _build(self, dtype, device):
         e = chunk_elems(dtype)
@@ -302,27 +343,51 @@ class SpectralNormBank:
         self._table_host = table
         self.scratch_floats, self.pack_bytes = scratch_off, pack_off
         self.max_rows, self.max_cols, self.max_pack, self.pack_blocks = max_rows, max_cols, max_pack, pack_blocks
-        # gradient arena: per layer [dW (forward packing, fp32) | dot | dbias(rows)], and the flat d weight_orig buffer
-        btab = (L.SpSnBwdLayer * len(self.specs))()
-        arena_off, grad_off, max_elems, bias_off = 0, 0, 1, 0
-        self.grad_layout, self.grad_offs, self.bias_offs = [], [], []
+        # groups of consecutive layers with about the same number of weights each (forward order)
+        n = len(self.entries)
+        sizes = [ent.rows * ent.cols for ent in self.entries]
+        total, k = sum(sizes), min(self.N_GROUPS, n)
+        self.groups, lo, acc = [], 0, 0
+        for i in range(n):
+            acc += sizes[i]
+            left_groups, left_layers = k - len(self.groups) - 1, n - i - 1
+            if left_groups > 0 and left_layers >= left_groups and (acc >= total * (len(self.groups) + 1) / k or left_layers == left_groups):
+                self.groups.append((lo, i + 1))
+                lo = i + 1
+        self.groups.append((lo, n))
+        # gradient arena (per pass): per layer [dW (forward packing, fp32) | dot | dbias(rows)]; flat gradient buffer (persistent
+        # in direct mode): per group [d weight_orig of its layers | d bias of its layers], then the non-SN parameters
+        btab = (L.SpSnBwdLayer * n)()
+        arena_off, max_elems = 0, 1
+        self.grad_layout = []
         for i, ent in enumerate(self.entries):
             n_dw = ent.rows * ent.cols if ent.kind == 1 else ent.rows * ent.taps * ent.cin_p
             dw_off, dot_off, db_off = arena_off, arena_off + n_dw, arena_off + n_dw + 1
             arena_off = pad_to(db_off + ent.rows, 4)
             b = btab[i]
-            b.w, b.dw_off, b.dot_off, b.scratch_off, b.grad_off = ent.w, dw_off, dot_off, ent.scratch_off, grad_off
+            b.w, b.dw_off, b.dot_off, b.scratch_off = ent.w, dw_off, dot_off, ent.scratch_off
             b.rows, b.cols, b.cin, b.taps, b.cin_p, b.plain = ent.rows, ent.cols, ent.cin, ent.taps, ent.cin_p, ent.kind
-            b.db_off, b.bias_off = db_off, bias_off
-            self.bias_offs.append(bias_off)
-            bias_off += pad_to(ent.rows, 4)
+            b.db_off = db_off
             self.grad_layout.append((dw_off, n_dw, db_off))
-            self.grad_offs.append(grad_off)
-            grad_off += pad_to(ent.rows * ent.cols, 4)
             max_elems = max(max_elems, ent.rows * ent.cols)
-        self.arena_floats, self.grad_floats, self.max_elems = arena_off, grad_off, max_elems
-        self.bias_floats = bias_off
-        self.flat_w = self.flat_b = None           # (re)allocated by enter_backward()
+        flat_off = 0
+        self.grad_offs, self.bias_offs, self.group_range = [0] * n, [0] * n, []
+        for lo, hi in self.groups:
+            g0 = flat_off
+            for i in range(lo, hi):
+                self.grad_offs[i] = btab[i].grad_off = flat_off
+                flat_off += pad_to(self.entries[i].rows * self.entries[i].cols, 4)
+            for i in range(lo, hi):
+                self.bias_offs[i] = btab[i].bias_off = flat_off
+                flat_off += pad_to(self.entries[i].rows, 4)
+            self.group_range.append((g0, flat_off))
+        self.sn_floats = flat_off
+        self.extra_offs = []
+        for p in self.extra_params:
+            self.extra_offs.append(flat_off)
+            flat_off += pad_to(p.numel(), 4)
+        self.arena_floats, self.flat_floats, self.max_elems = arena_off, flat_off, max_elems
+        self.flat = None                           # (re)allocated by enter_backward()
         self.bwd_table_dev = torch.frombuffer(bytearray(bytes(btab)), dtype=torch.uint8).to(device)
 
     def begin(self, training: bool, dtype, device) -> SNCall:
@@ -339,12 +404,29 @@ class SpectralNormBank:
         weights = [m.weight_orig for m, _, _ in self.specs]
         self.handles = None
         if torch.is_grad_enabled() and any(w.requires_grad for w in weights):
-            self.handles = _SNBankFn.apply(call, *weights)
+            hs = []
+            for g, (lo, hi) in enumerate(self.groups):
+                hs.extend(_SNBankFn.apply(call, g, *weights[lo:hi]))
+            self.handles = hs
         return call
 
     def end(self) -> None:
         self.current = None
         self.handles = None
+
+    def flat_ranges(self, bucket_floats: int):
+        """Contiguous [start, stop) ranges covering the whole flat gradient buffer, the groups that finish first in a backward pass
+        (the last ones in forward order) first, each cut into buckets of at most `bucket_floats`."""
+        out = []
+        spans = list(reversed(self.group_range))
+        if self.flat_floats > self.sn_floats:
+            spans.append((self.sn_floats, self.flat_floats))
+        for a, b in spans:
+            while a < b:
+                e = min(b, a + bucket_floats)
+                out.append((a, e))
+                a = e
+        return out
 
 
 def packed_layer(module, training: bool, dtype, device) -> PackedLayer:
@@ -367,8 +449,17 @@ def packed_layer(module, training: bool, dtype, device) -> PackedLayer:
 # ======================================================================================================
 # convolution / linear
 # ======================================================================================================
-# bench.py sets this to a list to time one kernel family with events on the launch stream: entries (start, end, flops)
+# bench.py sets this to a list to time the convolution launches with events on the launch stream (eager steps only): entries
+# (start, end, algorithmic flops, family in {"fwd", "dgrad", "wgrad"}, is_dominant_kernel)
 KERNEL_PROBE = None
+
+
+def _probed(family: str, flops: float, dominant: bool, fn) -> None:
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    KERNEL_PROBE.append((e0, e1, flops, family, dominant))
 
 
 def _is_halo128(n, h, w, cout, ksize) -> bool:
@@ -396,13 +487,10 @@ def set_tuning(key: int, value: int) -> None:
 
 
 def conv_launch(x, w_ptr: int, bias, y, res1, res2, mask_src, slope: float, n, h, w, cin_p, cout, ldy, ksize, act,
-                dtype, pool2: bool = False, in_up2: bool = False) -> None:
-    if KERNEL_PROBE is not None and _is_halo128(n, h, w, cout, ksize):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        _conv_launch(x, w_ptr, bias, y, res1, res2, mask_src, slope, n, h, w, cin_p, cout, ldy, ksize, act, dtype, pool2, in_up2)
-        e1.record()
-        KERNEL_PROBE.append((e0, e1, 2.0 * n * h * w * cin_p * cout * ksize * ksize))
+                dtype, pool2: bool = False, in_up2: bool = False, family: str = "fwd") -> None:
+    if KERNEL_PROBE is not None:
+        _probed(family, 2.0 * n * h * w * cin_p * cout * ksize * ksize, _is_halo128(n, h, w, cout, ksize),
+                lambda: _conv_launch(x, w_ptr, bias, y, res1, res2, mask_src, slope, n, h, w, cin_p, cout, ldy, ksize, act, dtype, pool2, in_up2))
         return
     _conv_launch(x, w_ptr, bias, y, res1, res2, mask_src, slope, n, h, w, cin_p, cout, ldy, ksize, act, dtype, pool2, in_up2)
 
@@ -527,7 +615,7 @@ class _ConvFn(torch.autograd.Function):
             dx = (nhwc_empty if pl.cin == cin_p else nhwc_zeros)(n, cin_p, h, w, dt, x.device)
             # mask_input: x is the LeakyReLU output of a `premasked` producer - multiply dx by lrelu'(x) in the epilogue
             conv_launch(dz, pl.dgrad, None, dx, None, None, x if ctx.mask_input else None, 0.2, n, h, w, pl.cout_p, pl.cin, cin_p,
-                        ksize, ACT_NONE, dt, in_up2=up2)
+                        ksize, ACT_NONE, dt, in_up2=up2, family="dgrad")
         if need[1]:
             # weight (+ bias) gradient accumulate into this layer's slots of the pass-wide arena; the spectral-norm
             # backward of all layers runs later, batched, in _SNBankFn.backward
@@ -536,8 +624,13 @@ class _ConvFn(torch.autograd.Function):
                 db = pl.call.db_slot(pl)
             ws = torch.empty(ws_floats, dtype=torch.float32, device=x.device) if ws_floats else None
             direct_bias = db is not None and pl.call.bank.direct_grads
-            L.call("sp_conv2d_wgrad_accum_pooled" if up2 else "sp_conv2d_wgrad_accum", ptr(x), ptr(dz), ptr(dwsn), ptr(db), ptr(ws), ws_floats, n, h, w, cin_p, cout, cout_p, ksize,
-                   sp_dtype(dt), stream())
+            def launch_wgrad():
+                L.call("sp_conv2d_wgrad_accum_pooled" if up2 else "sp_conv2d_wgrad_accum", ptr(x), ptr(dz), ptr(dwsn), ptr(db), ptr(ws),
+                       ws_floats, n, h, w, cin_p, cout, cout_p, ksize, sp_dtype(dt), stream())
+            if KERNEL_PROBE is not None:
+                _probed("wgrad", 2.0 * n * h * w * cin_p * cout * ksize * ksize, False, launch_wgrad)
+            else:
+                launch_wgrad()
             dh = _zero1(x.device)
             if direct_bias:
                 db = None                # accumulated in the bank's persistent slot; _SNBankFn.backward assigns bias.grad

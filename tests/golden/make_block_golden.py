@@ -111,7 +111,7 @@ def run_losses(lossfunction, arrays, meta):
         arrays["lsgan/gin/" + k] = v.grad.numpy()
     arrays["lsgan/out"] = np.array([float(lr), float(lf), float(lg)], dtype=np.float32)
     # a13: 5 spatial levels + the two vector levels, as the pyramid has them (tiny extents)
-    shapes = [(2, 4, 16, 16), (2, 6, 8, 8), (2, 8, 4, 4), (2, 8, 2, 2), (2, 4, 2, 2), (2, 24), (2, 10)]
+    shapes = [(2, 4, 16, 16), (2, 8, 8, 8), (2, 8, 4, 4), (2, 8, 2, 2), (2, 4, 2, 2), (2, 24), (2, 10)]       # channel counts: multiples of 4, like the pyramid's
     real = [rnd(*s, seed=20 + i) for i, s in enumerate(shapes)]
     fake = [rnd(*s, seed=30 + i).requires_grad_(True) for i, s in enumerate(shapes)]
     masks = [(torch.rand(s[0], 1, *s[2:], generator=torch.Generator().manual_seed(40 + i)) < 0.5).float() if len(s) == 4

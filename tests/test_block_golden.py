@@ -36,10 +36,12 @@ def block_state(name, prefix=""):
     return {prefix + k: T("%s/param/%s" % (name, k)).clone() for k in META[name]["state_keys"]}
 
 
-def assert_close(got, ref, tol, what):
+def assert_close(got, ref, tol, what, floor=1e-6):
+    """max |err| <= tol * max(max|ref|, floor).  ``floor``: magnitude below which a tensor is rounding noise - the gradient of a
+    bias that feeds a BatchNorm is exactly zero in exact arithmetic and ~1e-6 of the other gradients in fp32."""
     got, ref = got.detach().float().cpu(), ref.float()
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
-    scale = max(float(ref.abs().max()), 1e-6)
+    scale = max(float(ref.abs().max()), floor)
     err = float((got - ref).abs().max())
     assert err <= tol * scale, "%s: max err %.3e vs scale %.3e (tol %.1e)" % (what, err, scale, tol)
 
@@ -64,9 +66,11 @@ def test_oracle_block_matches_reference(name):
     assert_close(out, T(name + "/out"), 1e-5, "out")
     for k in META[name]["diff_inputs"]:
         assert_close(ins[k].grad, T("%s/gin/%s" % (name, k)), 2e-5, "d" + k)
+    gscale = max(float(T("%s/grad/%s" % (name, k)).abs().max()) for k in META[name]["param_names"])
     for k in META[name]["param_names"]:
         g = S["b." + k].grad
-        assert_close(g if g is not None else torch.zeros_like(S["b." + k]), T("%s/grad/%s" % (name, k)), 5e-5, "grad " + k)
+        assert_close(g if g is not None else torch.zeros_like(S["b." + k]), T("%s/grad/%s" % (name, k)), 5e-5, "grad " + k,
+                     floor=1e-2 * gscale)
     for key in ARR:
         if key.startswith(name + "/buf/"):
             k = key[len(name) + 5:]
@@ -157,9 +161,11 @@ def test_hip_block_matches_reference(name):
     for k, leaf in leaves.items():
         assert_close(leaf.grad, T("%s/gin/%s" % (name, k)), tol, "d" + k)
     params = dict(m.named_parameters())
+    gscale = max(float(T("%s/grad/%s" % (name, k)).abs().max()) for k in META[name]["param_names"])
     for k in META[name]["param_names"]:
         g = params[k].grad
-        assert_close(g if g is not None else torch.zeros_like(params[k]), T("%s/grad/%s" % (name, k)), 2 * tol, "grad " + k)
+        assert_close(g if g is not None else torch.zeros_like(params[k]), T("%s/grad/%s" % (name, k)), 2 * tol, "grad " + k,
+                     floor=1e-2 * gscale)
     sd = m.state_dict()
     for key in ARR:
         if key.startswith(name + "/buf/"):

@@ -1,6 +1,7 @@
-"""Multi-process data-parallel contract on CPU (gloo, world_size 2): after GradientReducer.reduce every rank
-holds the AVERAGE over ranks of the single-rank gradients computed on its shard with identical parameters
-(SURVEY.md section 8e).  The arithmetic here is the CPU oracle - the reducer is what is under test."""
+"""Multi-process data-parallel contract on CPU (gloo, world_size 2): after the reducer every rank holds the AVERAGE over ranks
+of the single-rank gradients computed on its shard with identical parameters.  The arithmetic here is
+the CPU oracle - the reducer is what is under test: the flat, in-place path the training step uses (ranges of ONE gradient
+buffer handed over group by group, ops.SpectralNormBank.flat) and the per-parameter fallback."""
 import os
 import socket
 
@@ -47,6 +48,91 @@ def _worker(rank, world, port, bucket_bytes, results):
         results[rank] = err
     finally:
         dist.destroy_process_group()
+
+
+def _flat_worker(rank, world, port, bucket_bytes, results):
+    """The training step's path: every gradient of the network is a view of one flat fp32 buffer; ranges of it are reduced in
+    place - first the 'groups' that finish early in a backward pass (the tail of the buffer), then whatever is left."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from semantic_pyramid_for_image_generation_amd.distributed import GradientReducer
+        _, plist = _shard_grads(rank)
+        expected = None
+        for r in range(world):
+            _, pl = _shard_grads(r)
+            g = [p.grad.clone() for p in pl]
+            expected = g if expected is None else [a + b for a, b in zip(expected, g)]
+        expected = [e / world for e in expected]
+        offs, total = [], 0
+        for p in plist:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        flat = torch.zeros(total)
+        for p, o in zip(plist, offs):
+            flat[o:o + p.numel()].copy_(p.grad.flatten())
+            p.grad = flat[o:o + p.numel()].view(p.shape)                     # .grad are views: reduced in place
+        red = GradientReducer(bucket_bytes=bucket_bytes)
+        cut = offs[len(offs) * 3 // 4]
+        bucket = max(1, bucket_bytes // 4)
+        for a in range(cut, total, bucket):                                  # a late layer group reports first ...
+            red.reduce_range(flat, a, min(total, a + bucket))
+        red.reduce_flat(flat, [(a, min(cut, a + bucket)) for a in range(0, cut, bucket)])       # ... the rest after backward
+        covered = sorted(red.log)
+        assert covered[0][0] == 0 and covered[-1][1] == total and all(x[1] == y[0] for x, y in zip(covered, covered[1:]))
+        red.join()
+        err = max(float((p.grad - e).abs().max() / (e.abs().max() + 1e-12)) for p, e in zip(plist, expected))
+        results[rank] = (err, all(p.grad.data_ptr() == flat.data_ptr() + 4 * o for p, o in zip(plist, offs)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bucket_bytes", [1 << 16, 32 << 20])
+def test_flat_in_place_reduction_averages_shard_gradients(bucket_bytes):
+    world = 2
+    port = _free_port()
+    with mp.Manager() as mgr:
+        results = mgr.dict()
+        mp.spawn(_flat_worker, args=(world, port, bucket_bytes, results), nprocs=world, join=True)
+        assert len(results) == world
+        for r in range(world):
+            err, in_place = results[r]
+            assert err <= 1e-6 and in_place, (r, results[r])
+
+
+def test_bank_flat_layout_covers_every_parameter_once():
+    """ops.SpectralNormBank's flat gradient layout (host logic, no kernels): every parameter of G / D owns exactly one slot,
+    the layer groups are contiguous, and flat_ranges() tiles the buffer - the groups that finish first in backward first."""
+    import semantic_pyramid_for_image_generation_amd as sp
+    for net in (sp.Generator(channels_factor=8), sp.Discriminator(channel_factor=8)):
+        bank = net._bank
+        bank._build(torch.float32, "cpu")
+        bank._alloc_flat("cpu")
+        views = bank.w_views + [v for v, (m, _, _) in zip(bank.b_views, bank.specs) if hasattr(m, "bias")] + bank.extra_views
+        params = [m.weight_orig for m, _, _ in bank.specs] + [m.bias for m, _, _ in bank.specs if hasattr(m, "bias")] + bank.extra_params
+        assert {id(p) for p in params} == {id(p) for p in net.parameters()}
+        spans = sorted((v.data_ptr(), v.data_ptr() + 4 * v.numel()) for v in views)
+        assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))                       # no overlap
+        assert spans[0][0] >= bank.flat.data_ptr() and spans[-1][1] <= bank.flat.data_ptr() + 4 * bank.flat_floats
+        assert [g[0] for g in bank.group_range[1:]] == [g[1] for g in bank.group_range[:-1]] and bank.group_range[0][0] == 0
+        ranges = bank.flat_ranges(1 << 18)
+        assert ranges[0][0] == bank.group_range[-1][0]                                    # the last group leads
+        cov = sorted(ranges)
+        assert cov[0][0] == 0 and cov[-1][1] == bank.flat_floats and all(x[1] == y[0] for x, y in zip(cov, cov[1:]))
+
+
+def test_bench_spawns_its_own_ranks():
+    """bench.py --gpus N without an outer launcher: N children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set and
+    rendezvous on 127.0.0.1; the parent (which never touches the GPU) relays rank 0's output and the worst exit code."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys; sys.argv = ['bench.py', '--gpus', '3']; sys.path.insert(0, %r); import bench; "
+            "bench.__file__ = %r; sys.exit(bench.spawn_ranks(3))") % (root, os.path.join(root, "tests", "_rank_echo.py"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip() == "rank 0 of 3 local 0 master 127.0.0.1", out.stdout
 
 
 @pytest.mark.parametrize("bucket_bytes", [1 << 16, 32 << 20])

@@ -97,9 +97,14 @@ def test_checkpoint_round_trip_on_the_device(tmp_path):
     ck = torch.load(path, map_location="cpu")                                                # main.py:68-73
     assert all(any(k.endswith(s) for k in ck["generator"]) for s in ("weight_orig", "weight_u", "weight_v"))
     G2 = sp.Generator(channels_factor=4).cuda(); D2 = sp.Discriminator(channel_factor=4).cuda()
-    og2 = torch.optim.Adam(G2.parameters(), lr=1e-4); od2 = torch.optim.Adam(D2.parameters(), lr=1e-4)   # plain torch optimizers, as main.py:64-65
+    og2 = sp.optim.Adam(G2.parameters(), lr=1e-4); od2 = sp.optim.Adam(D2.parameters(), lr=1e-4)
     G2.load_state_dict(ck["generator"]); D2.load_state_dict(ck["discriminator"])
     og2.load_state_dict(ck["generator_optimizer"]); od2.load_state_dict(ck["discriminator_optimizer"])
+    # the same file restores plain torch optimizers (what main.py:64-65 constructs): same keys, steps and moment shapes
+    ot = torch.optim.Adam(sp.Generator(channels_factor=4).cuda().parameters(), lr=1e-4)
+    ot.load_state_dict(ck["generator_optimizer"])
+    p0 = ot.param_groups[0]["params"][0]
+    assert float(ot.state[p0]["step"]) == 1.0 and ot.state[p0]["exp_avg"].shape == p0.shape and ot.state[p0]["exp_avg"].is_cuda
     mw2 = sp.ModelWrapper(generator=G2, discriminator=D2, vgg16=V, training_dataset=None, validation_dataset=None,
                           generator_optimizer=og2, discriminator_optimizer=od2, save_data_path=None)
     G2.train(); D2.train()
@@ -107,9 +112,8 @@ def test_checkpoint_round_trip_on_the_device(tmp_path):
     for n in LOSS_NAMES:
         assert float(got[n]) == float(ref[n]), n
     assert torch.equal(got["images_fake"], ref["images_fake"])
-    # torch's own Adam arithmetic (foreach kernels) vs sp_adam_multi: same operation order, compared to fp32 rounding
-    for k, v in G2.state_dict().items():
-        assert torch.allclose(v.float(), ref_state[k].float(), rtol=1e-6, atol=1e-8), k
+    for k, v in G2.state_dict().items():                      # parameters, spectral-norm vectors, BatchNorm statistics, counters
+        assert torch.equal(v, ref_state[k]), k
 
 
 def test_vgg16_constructor_loads_a_pretrained_file(tmp_path):
