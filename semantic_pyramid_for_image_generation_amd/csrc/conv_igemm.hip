@@ -224,14 +224,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(sp_conv_params p) {
 
 
 template <typename T>
-__device__ __forceinline__ void conv_epilogue4(const sp_conv_params& p, float (&v)[4], long pix, int co, bool vec_ok) {
+__device__ __forceinline__ void conv_epilogue4(const sp_conv_params& p, float (&v)[4], long pix, int co, bool vec_ok, bool add_bias = true) {
     T* __restrict__ yg = reinterpret_cast<T*>(p.y);
     const T* r1 = reinterpret_cast<const T*>(p.res1);
     const T* r2 = reinterpret_cast<const T*>(p.res2);
     const T* ms = reinterpret_cast<const T*>(p.mask_src);
     const long off = pix * p.ldy + co;
     if (vec_ok) {
-        if (p.bias) {
+        if (p.bias && add_bias) {
             const float4 bv = *reinterpret_cast<const float4*>(p.bias + co);
             v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
         }
@@ -250,7 +250,7 @@ __device__ __forceinline__ void conv_epilogue4(const sp_conv_params& p, float (&
         for (int r = 0; r < 4; ++r) {
             if (co + r >= p.cout) break;
             float sv = v[r];
-            if (p.bias) sv += p.bias[co + r];
+            if (p.bias && add_bias) sv += p.bias[co + r];
             if (ms) sv *= (Elem<T>::ld(ms + off + r) > 0.f ? 1.f : p.mask_neg_slope);
             if (r1) sv += Elem<T>::ld(r1 + off + r);
             if (r2) sv += Elem<T>::ld(r2 + off + r);
@@ -287,14 +287,14 @@ template <> struct Wide16<float> {
     }
 };
 template <typename T>
-__device__ __forceinline__ void conv_epilogue16(const sp_conv_params& p, float (&v)[16], long pix, int co) {
+__device__ __forceinline__ void conv_epilogue16(const sp_conv_params& p, float (&v)[16], long pix, int co, bool add_bias = true) {
     T* __restrict__ yg = reinterpret_cast<T*>(p.y);
     const T* r1 = reinterpret_cast<const T*>(p.res1);
     const T* r2 = reinterpret_cast<const T*>(p.res2);
     const T* ms = reinterpret_cast<const T*>(p.mask_src);
     const long off = pix * p.ldy + co;
     float t[16];
-    if (p.bias) {
+    if (p.bias && add_bias) {
         Wide16<float>::ld(p.bias + co, t);
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] += t[r];
@@ -330,7 +330,7 @@ __device__ __forceinline__ float dpp_xor1(float v) {
 __device__ __forceinline__ float pool2_combine(float x, float y, bool is_max) { return is_max ? fmaxf(x, y) : x + y; }
 template <typename T>
 __device__ __forceinline__ void conv_epilogue_pool2(const sp_conv_params& p, const float (&a)[16], const float (&b)[16], int lane,
-                                                    long ppix_row, int pcol0, int co) {
+                                                    long ppix_row, int pcol0, int co, bool add_bias = true) {
     const bool odd = lane & 1;
     const bool is_max = p.pool2 == 2;
     float v[16];
@@ -340,7 +340,7 @@ __device__ __forceinline__ void conv_epilogue_pool2(const sp_conv_params& p, con
         const float mine = odd ? b[c] : a[c];
         v[c] = is_max ? fmaxf(mine, recv) : (mine + recv) * 0.25f;
     }
-    conv_epilogue16<T>(p, v, ppix_row + pcol0 + (odd ? 8 : 0) + ((lane & 15) >> 1), co);
+    conv_epilogue16<T>(p, v, ppix_row + pcol0 + (odd ? 8 : 0) + ((lane & 15) >> 1), co, add_bias);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -972,11 +972,39 @@ __global__ __launch_bounds__(512) void conv3x3_tall_kernel(sp_conv_params p, int
     for (int ds = 0; ds < 3; ++ds)
         b_addr[ds] = lds_base + ((RW * wpx) * HP + frow + ds) * 64 + ((fslot ^ (((frow + ds) >> 1) & 3)) << 4);
 
+    // The accumulators of an item START at the bias of its output channels (lane (pixel, g): channels g*16 + i*4 + r): the
+    // bias loads are issued right behind the previous item's stores, where the pipeline waits for memory anyway, instead of
+    // in front of every fragment's stores - the epilogue of a bias-only layer then has no load in its dependency chain
+    // (per-item overhead was ~5 us of a 20 us item).  Average / max pooling commute with the bias; the x1/4 of the pooled
+    // input gradient (in_up2) would scale it, so those launches (which carry no bias anyway) keep the epilogue form.
+    const bool bias_in_acc = p.bias != nullptr && !up;
     f32x4_t acc[4][NFR];
+    auto init_acc = [&](int it) {
+        f32x4_t b4[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) b4[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (bias_in_acc && it < my_items) {
+            int n, ty0, tx0, co0;
+            item_coords(it, n, ty0, tx0, co0);
+            const int cb = co0 + wco * 64 + (lane >> 4) * 16;
 #pragma unroll
-        for (int j = 0; j < NFR; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < 4; ++i) {
+                const int co = cb + i * 4;
+                if (co + 3 < p.cout) {
+                    const float4 t = *reinterpret_cast<const float4*>(p.bias + co);
+                    b4[i] = f32x4_t{t.x, t.y, t.z, t.w};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) b4[i][r] = co + r < p.cout ? p.bias[co + r] : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NFR; ++j) acc[i][j] = b4[i];
+    };
+    init_acc(0);
 
     // one tap column ds of one chunk: 12 A + 2*NB B fragment reads, 24*RW MFMAs.  Halo row h (relative to the wave's
     // first output row) is read once and used by tap rows dr = 0..2 for output row h - dr.  Reads of row h+1 (and the A
@@ -1083,7 +1111,7 @@ __global__ __launch_bounds__(512) void conv3x3_tall_kernel(sp_conv_params p, int
                                 b[i * 4 + r] = pool2_combine(acc[i][j + 1][r], acc[i][j + 3][r], p.pool2 == 2);
                             }
                         const long prow = ((long)n * (H >> 1) + ((ty0 + RW * wpx + (j >> 1)) >> 1)) * (W >> 1);
-                        conv_epilogue_pool2<T>(p, a, b, lane, prow, tx0 >> 1, co_b);
+                        conv_epilogue_pool2<T>(p, a, b, lane, prow, tx0 >> 1, co_b, !bias_in_acc);
                     }
                 } else if (wide) {
                     float v[16];
@@ -1091,22 +1119,21 @@ __global__ __launch_bounds__(512) void conv3x3_tall_kernel(sp_conv_params p, int
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r];
-                    conv_epilogue16<T>(p, v, pix, co_b);
+                    conv_epilogue16<T>(p, v, pix, co_b, !bias_in_acc);
                 } else {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int co = co_b + i * 4;
                         if (co < p.cout) {
                             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                            conv_epilogue4<T>(p, v, pix, co, vec_ok);
+                            conv_epilogue4<T>(p, v, pix, co, vec_ok, !bias_in_acc);
                         }
                     }
                 }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             });
             kc = 0;
             ++item;
+            init_acc(item);
         } else {
             ++kc;
         }
