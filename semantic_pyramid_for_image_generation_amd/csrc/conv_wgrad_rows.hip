@@ -406,12 +406,22 @@ int sp_wgrad_rows_launch(const void* x, const void* dy, float* dw, float* dbias,
     if (total > 512) total = 512;
     int target = (total + pairs / 2) / pairs;
     if (target < 1) target = 1;
-    // units = (image, strip, row chunk): at least `target` of them, chunks as long as possible (a unit re-reads two halo rows)
-    int ru = h;
-    while (ru > 8 && ru % 2 == 0 && (ru / 2) % WR_R == 0 && (long)n * (w / 32) * (h / ru) < target) ru /= 2;
+    // units = (image, strip, row chunk of ru rows); block b takes units b, b + nblk, ...  Time ~ (units per block) x ru image rows,
+    // so ru and nblk are chosen to make every block walk the same number of rows: k = ceil(units / target) units each,
+    // nblk = ceil(units / k) blocks, cost k * ru - minimised over the power-of-two chunk heights down to 8 rows (a unit
+    // re-reads two halo rows, so ties go to the longer chunk).  The first version took the longest chunk that gave >= target
+    // units: 40 units on 32 blocks (256 -> 256 @64^2, batch 20) left 24 blocks idle half of the time (cost 128 instead of 80).
+    int ru = h, best_cost = 1 << 30, nblk = 1;
+    for (int r = h; r >= 8 || r == h; r /= 2) {
+        if (r % WR_R != 0) break;
+        const long units = (long)n * (w / 32) * (h / r);
+        const long k = (units + target - 1) / target;
+        const long cost = k * (r + 1);                     // + 1: a mild preference for long chunks beyond exact ties
+        if (cost < best_cost) { best_cost = (int)cost; ru = r; nblk = (int)((units + k - 1) / k); }
+        if (r % 2 != 0 || r / 2 < 8) break;
+    }
     a.rows_per_unit = ru;
     a.units = n * (w / 32) * (h / ru);
-    int nblk = a.units < target ? a.units : target;
     // the slab area holds 512 partial tiles; the deterministic mode must not fall back to atomics with several blocks per pair
     if (det && (long)nblk * pairs > 512) nblk = 512 / pairs > 0 ? 512 / pairs : 1;
     static bool attr_set = false;
