@@ -840,7 +840,7 @@ template <int N> __device__ __forceinline__ void wait_lgkm() {
 // TH = patch height: 16 (the tall tile) or 8 (WCO = 2 only: the halo kernel's 128 co x 8x32 tile on this kernel's LDS-DMA
 // pipeline; a wave then owns 2 rows, 64 accumulator registers, and keeps all 12 A fragments of a stage live: IH = 1).
 template <typename T, int WCO, int TH = 16>
-__global__ __launch_bounds__(512) void conv3x3_tall_kernel(sp_conv_params p, int cotiles, int total) {
+__global__ __launch_bounds__(512) void conv3x3_tall_kernel(sp_conv_params p, int cotiles, int total, int stagger) {
     constexpr int TL_TH = TH, TL_HR = TH + 2;          // shadow the file-scope constants
     constexpr int E = 16 / (int)sizeof(T);
     constexpr int KC = 4 * E;                    // channels per 64-byte chunk
@@ -1012,7 +1012,7 @@ __global__ __launch_bounds__(512) void conv3x3_tall_kernel(sp_conv_params p, int
     // WCO = 2 walks the column twice, two co-fragments at a time: 24 fewer live fragment registers (128 accumulators leave
     // no room for 12 A fragments), at 36 instead of 24 LDS reads per 96 MFMAs.
     constexpr int IH = (WCO == 2 && RW == 4) ? 2 : 1, IW = 4 / IH;
-    auto stage = [&](auto ds_c, unsigned ab, unsigned bb) {
+    auto stage = [&](auto ds_c, unsigned ab, unsigned bb, auto&& mid) {
         constexpr int DS = decltype(ds_c)::value;
         // byte offset of tap (dr, DS) inside the weight stage
         constexpr int TAP_STRIDE = CO_T * 64;
@@ -1044,11 +1044,13 @@ __global__ __launch_bounds__(512) void conv3x3_tall_kernel(sp_conv_params p, int
                             for (int hh = 0; hh < 2; ++hh) Mma<T>::run(a[dr][i], bf[h][hh], acc[i0 + i][rr * 2 + hh]);
                     }
                 });
+                if constexpr (h == 1 && decltype(ihc)::value == 0) mid();      // behind the second halo row's MFMAs (see the main loop)
             });
         });
     };
 
     if (nchunks <= 0) return;
+    const bool late = stagger != 0 && wave >= 4;           // wave-uniform (wave comes from readfirstlane)
     set_halo_desc(0);
     set_w_desc(0);
     issue_halo(0);
@@ -1064,24 +1066,33 @@ __global__ __launch_bounds__(512) void conv3x3_tall_kernel(sp_conv_params p, int
             constexpr int st = decltype(sc)::value;       // stage inside the chunk
             wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();                  // stage g landed for everyone; everyone left stage g - 1
-            // request the next stage (and, at the first stage of a chunk, the next chunk's halo)
-            if (st + 1 < SPC) {
-                issue_w(gc, st + 1, (g + 1) & 1);
-            } else if (more_chunks) {
-                if (item_ends) set_w_desc(item + 1);      // first request for the next item
-                issue_w(gc + 1, 0, (g + 1) & 1);
-            }
-            if (st == 0 && more_chunks) {
-                if (item_ends) set_halo_desc(item + 1);
-                issue_halo(gc + 1);
-            }
+            // request the next stage (and, at the first stage of a chunk, the next chunk's halo).  The two waves of a SIMD
+            // would otherwise both spend the head of the stage issuing LDS-DMA (3 - 9 wave-instructions of ~60+ issue cycles
+            // each) and then both wait for their first fragments: the matrix pipe idles.  The second-dispatched half of the
+            // block (waves 4 - 7: one per SIMD) therefore issues ITS requests a third of the way into its MFMA stream, when the
+            // first half is multiplying (SP_TUNE_CONV_STAGGER; default: on for the 16-row 128-co tile only, see launch_tall).
+            auto request = [&]() {
+                if (st + 1 < SPC) {
+                    issue_w(gc, st + 1, (g + 1) & 1);
+                } else if (more_chunks) {
+                    if (item_ends) set_w_desc(item + 1);      // first request for the next item
+                    issue_w(gc + 1, 0, (g + 1) & 1);
+                }
+                if (st == 0 && more_chunks) {
+                    if (item_ends) set_halo_desc(item + 1);
+                    issue_halo(gc + 1);
+                }
+            };
+            if (!late) request();
             const unsigned ab = a_addr + (unsigned)((g & 1) * W_BYTES);
+            auto deferred = [&]() { if (late) request(); };
+            auto nothing = []() {};
             if constexpr (SPC == 3) {
-                stage(std::integral_constant<int, st>{}, ab, b_addr[st] + hb);
+                stage(std::integral_constant<int, st>{}, ab, b_addr[st] + hb, deferred);
             } else {
-                stage(std::integral_constant<int, 0>{}, ab, b_addr[0] + hb);
-                stage(std::integral_constant<int, 1>{}, ab, b_addr[1] + hb);
-                stage(std::integral_constant<int, 2>{}, ab, b_addr[2] + hb);
+                stage(std::integral_constant<int, 0>{}, ab, b_addr[0] + hb, deferred);
+                stage(std::integral_constant<int, 1>{}, ab, b_addr[1] + hb, nothing);
+                stage(std::integral_constant<int, 2>{}, ab, b_addr[2] + hb, nothing);
             }
             ++g;
         });
@@ -1155,7 +1166,8 @@ int launch_tall(const sp_conv_params& p, hipStream_t s) {
     const int total = p.n * (p.h / TH) * (p.w_ / TL_TW) * cotiles;
     int grid = total < g_num_cu ? total : g_num_cu;        // persistent: one block per CU
     if (grid >= 8) grid -= grid % 8;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), LDS, s, p, cotiles, total);
+    // measured (scratch/ab_conv.py, profiles/README.md): staggering helps the 16-row 128-co tile (+3-5 %) and costs the 8-row one 4 %
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), LDS, s, p, cotiles, total, sp_tune(SP_TUNE_CONV_STAGGER, (WCO == 2 && TH == 16) ? 1 : 0));
     SP_LAUNCH_CHECK();
     return SP_OK;
 }
