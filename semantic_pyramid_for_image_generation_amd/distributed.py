@@ -24,9 +24,12 @@ import torch.distributed as dist
 
 
 class GradientReducer:
-    def __init__(self, bucket_bytes: int = 32 << 20, process_group=None) -> None:
+    def __init__(self, bucket_bytes: int = 32 << 20, process_group=None, single_rank_passthrough: bool = True) -> None:
+        """single_rank_passthrough=False keeps the whole machinery (side stream, events, collectives, scaling) running in a
+        group of ONE rank - the all-reduce is then the identity: how the single-GPU tests exercise the multi-GPU code path."""
         self.bucket_bytes = bucket_bytes
         self.group = process_group
+        self.passthrough = single_rank_passthrough
         self._side = None
         self._pending = 0
         self.log: List[Tuple[int, int]] = []       # (start, stop) of every range reduced since the last join (tests, DESIGN.md)
@@ -34,12 +37,16 @@ class GradientReducer:
     def world_size(self) -> int:
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
+    def active(self) -> bool:
+        """True if reductions are actually issued (more than one rank, or a one-rank group kept live for tests)."""
+        return dist.is_available() and dist.is_initialized() and (self.world_size() > 1 or not self.passthrough)
+
     # -------------------------------------------------------------------------------------------- flat, in place
     def reduce_range(self, flat: torch.Tensor, start: int, stop: int) -> None:
         """Average flat[start:stop] over all ranks, in place, asynchronously: the range must be final on the CURRENT stream at
         the time of the call (GPU: an event orders the side stream behind it).  join() makes the results visible."""
         ws = self.world_size()
-        if ws == 1 or stop <= start:
+        if not self.active() or stop <= start:
             return
         view = flat[start:stop]
         self.log.append((start, stop))
@@ -74,7 +81,7 @@ class GradientReducer:
         """Average ``p.grad`` of loose parameters (gradients that do not live in a bank's flat buffer: a network without
         direct gradients, or a caller's own modules): bucketed flatten -> all-reduce -> scatter back, joined at once."""
         ws = self.world_size()
-        if ws == 1:
+        if not self.active():
             return
         buckets, cur, size = [], [], 0
         for p in reversed(list(params)):          # reverse registration order ~ order in which backward finishes them

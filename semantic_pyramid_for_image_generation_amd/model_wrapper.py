@@ -103,7 +103,7 @@ class ModelWrapper(object):
             return
         bank.on_group_done = None
         self._fired = set()
-        if self.gradient_reducer is not None and not self._capturing and self.gradient_reducer.world_size() > 1:
+        if self.gradient_reducer is not None and not self._capturing and self.gradient_reducer.active():
             red = self.gradient_reducer
 
             def done(start, stop, bank=bank):
@@ -123,7 +123,7 @@ class ModelWrapper(object):
     def _start_reduce(self, key: str, params, eager: bool) -> None:
         """Enqueues (side stream) whatever of the network's gradients has not been handed over by the group hooks."""
         red = self.gradient_reducer
-        if red is None or red.world_size() == 1:
+        if red is None or not red.active():
             return
         bank = self._banks.get(key)
         if bank is None or bank.flat is None:

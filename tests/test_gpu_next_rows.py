@@ -136,3 +136,61 @@ def test_vgg16_constructor_loads_a_pretrained_file(tmp_path):
     assert len(fa) == 7
     for x, y in zip(fa, fb):
         assert torch.equal(x, y)
+
+
+def test_multi_gpu_code_path_in_a_one_rank_rccl_group():
+    """Row e on one GPU: a real RCCL process group of ONE rank with the reducer kept live (single_rank_passthrough=False), so the
+    side stream, the events, the in-place bucketed all-reduce of the flat gradient buffers, the group hooks of the eager
+    backward and the three-graph replay all run - the collective itself is the identity, so every result must be bit-identical
+    to the run without a reducer (fp32 mode: deterministic)."""
+    import torch.distributed as dist
+    from semantic_pyramid_for_image_generation_amd.distributed import GradientReducer
+    ops.set_compute_dtype(torch.float32)
+    batches = gu.golden_batches(4, 1)
+    noise = torch.randn(4, 4, 128, generator=torch.Generator().manual_seed(2)).cuda()
+
+    def run(reducer, graphed):
+        G, D, V = build(4, 1)
+        og, od = sp.optim.Adam(G.parameters(), lr=1e-4), sp.optim.Adam(D.parameters(), lr=1e-4)
+        mw = sp.ModelWrapper(generator=G, discriminator=D, vgg16=V, training_dataset=None, validation_dataset=None,
+                             generator_optimizer=og, discriminator_optimizer=od, save_data_path=None, gradient_reducer=reducer)
+        G.train(); D.train()
+        outs = []
+        images, labels, masks = batches[0]
+        images, labels, masks = images.cuda(), labels.cuda(), [m.cuda() for m in masks]
+        outs.append(mw.train_step(images, labels, masks, noise_d=noise[0], noise_g=noise[1]))
+        if graphed:
+            mw.capture_graphs(images, labels, masks)
+            out = mw.train_step_graphed(noise_d=noise[2], noise_g=noise[3])
+        else:
+            out = mw.train_step(images, labels, masks, noise_d=noise[2], noise_g=noise[3])
+        outs.append({k: v.clone() for k, v in out.items()})
+        torch.cuda.synchronize()
+        return outs, {k: v.detach().clone() for k, v in G.state_dict().items()}, {k: v.detach().clone() for k, v in D.state_dict().items()}
+
+    ref = run(None, False)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        for graphed in (False, True):
+            red = GradientReducer(bucket_bytes=1 << 20, single_rank_passthrough=False)
+            log = []
+            orig = red.reduce_range
+
+            def spy(flat, a, b, orig=orig, log=log):
+                log.append((flat.data_ptr(), a, b))
+                return orig(flat, a, b)
+            red.reduce_range = spy
+            got = run(red, graphed)
+            assert len(log) > 8, "no reduction was issued"
+            for it in range(2):
+                for n in LOSS_NAMES:
+                    assert float(got[0][it][n]) == float(ref[0][it][n]), (graphed, it, n)
+                assert torch.equal(got[0][it]["images_fake"], ref[0][it]["images_fake"]), (graphed, it)
+            for k in ref[1]:
+                assert torch.equal(got[1][k], ref[1][k]), (graphed, "G", k)
+            for k in ref[2]:
+                assert torch.equal(got[2][k], ref[2][k]), (graphed, "D", k)
+    finally:
+        dist.destroy_process_group()
