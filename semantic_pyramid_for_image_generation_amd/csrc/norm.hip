@@ -282,13 +282,21 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
         }
     }
     if (demb) {
-        // samples of one class share a row: one thread per channel adds them in batch order (no atomics, reproducible)
+        // samples of one class share a row: the FIRST sample of a class adds up all of them in batch order and stores the row
+        // once (no atomics, reproducible; plain independent stores - a read-modify-write per sample serialised 20 dependent
+        // memory round trips per launch).  The lanes of a channel split the samples.
         __syncthreads();
-        if (bl == 0 && c < C)
-            for (int n = 0; n < N; ++n) {
-                float* row = demb + (long)aff.cls[n] * 2 * C;
-                row[c] += embv[n][cl][0];
-                row[C + c] += embv[n][cl][1];
+        if (c < C)
+            for (int n = bl; n < N; n += FIN_NL) {
+                const long k = aff.cls[n];
+                bool first = true;
+                for (int m = 0; m < n; ++m) first = first && aff.cls[m] != k;
+                if (!first) continue;
+                float s0 = embv[n][cl][0], s1 = embv[n][cl][1];
+                for (int m = n + 1; m < N; ++m)
+                    if (aff.cls[m] == k) { s0 += embv[m][cl][0]; s1 += embv[m][cl][1]; }
+                demb[k * 2 * C + c] = s0;
+                demb[k * 2 * C + C + c] = s1;
             }
     }
     red[threadIdx.x * 4] = s1; red[threadIdx.x * 4 + 1] = s2; red[threadIdx.x * 4 + 2] = ga; red[threadIdx.x * 4 + 3] = gb;

@@ -86,6 +86,7 @@ class ModelWrapper(object):
                 if bank is not None:
                     bank.direct_grads = True
                     bank.expected_passes = passes
+                    bank.set_groups(4 if gradient_reducer is not None else 1)
                     self._banks[key] = bank
         self._graph_state = None
         self._capturing = False

@@ -107,8 +107,10 @@ def test_bank_flat_layout_covers_every_parameter_once():
     import semantic_pyramid_for_image_generation_amd as sp
     for net in (sp.Generator(channels_factor=8), sp.Discriminator(channel_factor=8)):
         bank = net._bank
+        bank.set_groups(4)
         bank._build(torch.float32, "cpu")
         bank._alloc_flat("cpu")
+        assert len(bank.groups) == 4
         views = bank.w_views + [v for v, (m, _, _) in zip(bank.b_views, bank.specs) if hasattr(m, "bias")] + bank.extra_views
         params = [m.weight_orig for m, _, _ in bank.specs] + [m.bias for m, _, _ in bank.specs if hasattr(m, "bias")] + bank.extra_params
         assert {id(p) for p in params} == {id(p) for p in net.parameters()}
