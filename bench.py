@@ -283,6 +283,15 @@ def sub_record(cf, batch, dtype_name, dev, steps, warmup, use_graphs):
     return rec
 
 
+def flush_c_stdio():
+    """RCCL writes its banner with C stdio, which is fully buffered on a pipe and would otherwise surface after the JSON line."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -297,6 +306,8 @@ def main():
     import torch.distributed as dist
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
+        dist.barrier()                               # creates the communicator now: RCCL prints its version banner here ...
+        flush_c_stdio()                              # ... through C stdio - push it out BEFORE the JSON line, not at exit
 
     cf = args.channel_factor if args.channel_factor != int(args.channel_factor) else int(args.channel_factor)
     job = Job(cf, args.batch, args.dtype, dev, world, rank, not args.no_graphs, args.device_masks)
@@ -351,6 +362,7 @@ def main():
                 line["batch32"]["note"] = "BASELINE.json config 2: one MI355X, batch 32"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cf)
+        flush_c_stdio()
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -1,6 +1,6 @@
 import csv, glob, collections, sys
 tag, pat = sys.argv[1], sys.argv[2]
-for i in (1, 2, 3):
+for i in (1, 2, 3, 4):
     fs = glob.glob('/root/repo/gpurun_out/pmc_%s/pass%d/*/*counter_collection.csv' % (tag, i))
     if not fs: continue
     agg = collections.defaultdict(list)
