@@ -7,7 +7,8 @@ B = 20
 dt = torch.bfloat16
 SHAPES = [(64, 64, 256, 3), (128, 128, 128, 3), (256, 256, 64, 3), (512, 512, 32, 3), (64, 128, 128, 3), (128, 256, 64, 3), (256, 512, 32, 3),
           (256, 256, 32, 3), (8, 64, 256, 3), (264, 256, 32, 3), (72, 64, 128, 3), (512, 512, 16, 3), (256, 256, 16, 3), (512, 512, 8, 3),
-          (768, 768, 4, 3), (128, 256, 32, 1), (64, 128, 64, 1)]
+          (768, 768, 4, 3), (128, 256, 32, 1), (64, 128, 64, 1), (256, 128, 32, 1), (128, 64, 64, 1), (8, 64, 128, 1), (256, 32, 32, 1), (256, 128, 16, 1),
+          (64, 128, 128, 1), (512, 256, 16, 1)]
 def timeit(fn, iters=20):
     for _ in range(3): fn()
     torch.cuda.synchronize()
