@@ -182,6 +182,38 @@ def test_conv_epilogue_act_and_residuals(dtype):
     close(m.weight_orig.grad, S["c.weight_orig"].grad, 2 * tol, "dW")
 
 
+SPLITK_1X1_CASES = [(768, 512, 1, 20, 2, 2), (512, 512, 1, 20, 4, 4), (256, 256, 1, 20, 8, 8), (520, 136, 1, 1, 5, 7), (256, 30, 1, 1, 6, 6),
+                    (128, 64, 1, 3, 3, 3), (512, 768, 1, 2, 2, 2)]
+
+
+@pytest.mark.parametrize("case", SPLITK_1X1_CASES)
+def test_conv1x1_splitk_kernel_bf16(case):
+    """conv1x1_splitk_kernel (small maps: the four waves of a block split K, partial tiles meet in LDS) at the step's own deep
+    shapes and on ragged ones: pixel counts that are no multiple of 32, Cin 520 (17 K-steps: unequal shares, a partial last
+    chunk), Cout 136 / 30 (partial channel tiles, scalar stores); forward here, input and weight gradients through dgrad."""
+    test_sn_conv_forward_backward(case, torch.bfloat16)
+
+
+def test_conv1x1_splitk_matches_direct_kernel_with_residuals():
+    """Same layer through both 1x1 kernels (tuning key CONV1X1_SPLITK) with bias, two residuals and the activation fused:
+    the results agree to bf16 rounding of one output."""
+    ops.set_compute_dtype(torch.bfloat16)
+    m = models.SNConv2d(512, 192, 1).cuda()
+    synth(m, 13, "c.")
+    x = dev(rnd(5, 512, 4, 4, seed=1), torch.bfloat16)
+    r1 = dev(rnd(5, 192, 4, 4, seed=2), torch.bfloat16)
+    r2 = dev(rnd(5, 192, 4, 4, seed=3), torch.bfloat16)
+    with torch.no_grad():
+        m.eval()
+        y_split = m(x, ops.ACT_LRELU, r1, r2).float()
+        ops.set_tuning(ops.TUNE_CONV1X1_SPLITK, 0)
+        try:
+            y_direct = m(x, ops.ACT_LRELU, r1, r2).float()
+        finally:
+            ops.set_tuning(ops.TUNE_CONV1X1_SPLITK, -1)
+    assert float((y_split - y_direct).abs().max()) <= 2 ** -7 * float(y_direct.abs().max())
+
+
 POOL2_CASES = [(64, 64, 2, 16, 32, 0), (64, 64, 2, 8, 32, 0), (64, 128, 2, 16, 32, 0), (128, 128, 3, 8, 64, 0), (40, 256, 1, 16, 32, 0),
                (64, 128, 2, 16, 32, 2), (64, 64, 5, 64, 128, 0), (64, 128, 5, 64, 128, 2)]
 
