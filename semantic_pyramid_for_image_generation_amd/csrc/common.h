@@ -143,3 +143,7 @@ static inline bool sp_deterministic(int dtype) { return sp_g_tune[SP_TUNE_DETERM
 int sp_wgrad_rows_launch(const void* x, const void* dy, float* dw, float* dbias, int n, int h, int w, int cin, int cout,
                          int ld_dy, float* ws, long ws_floats, int dy_up2, hipStream_t s);
 long sp_wgrad_rows_workspace(int n, int h, int w, int cin, int cout);
+// conv_wgrad_1x1.hip: same contract for the bf16 1x1 layers
+int sp_wgrad1x1_launch(const void* x, const void* dy, float* dw, float* dbias, int n, int h, int w, int cin, int cout, int ld_dy,
+                       float* ws, long ws_floats, hipStream_t s);
+long sp_wgrad1x1_workspace(int n, int h, int w, int cin, int cout, int ld_dy);

@@ -678,6 +678,11 @@ int dispatch_wgrad(const void* x, const void* dy, float* dw, int n, int h, int w
             if (rc != 1) return rc;
         }
     }
+    if (sizeof(T) == 2 && ksize == 1 && w_packed == nullptr && dot == nullptr) {
+        // streaming kernel of the 1x1 layers (conv_wgrad_1x1.hip): long-lived blocks, LDS-DMA ring, slabs + ordered reduce
+        const int rc = sp_wgrad1x1_launch(x, dy, dw, dbias, n, h, w, cin, cout, ld_dy, ws, ws_floats, s);
+        if (rc != 1) return rc;
+    }
     // throughput mode: the per-tap kernels keep their atomics (their slab mode measured slower); deterministic mode: slabs
     if (!det) { ws = nullptr; ws_floats = 0; }
     int co_t, ci_t;
@@ -715,6 +720,11 @@ extern "C" int sp_conv2d_wgrad_workspace(int32_t n, int32_t h, int32_t w_, int32
     SP_CHECK_ARG(floats_out && n > 0 && h > 0 && w_ > 0 && cin_p > 0 && cout > 0 && (ksize == 1 || ksize == 3), "sp_conv2d_wgrad_workspace: bad args");
     // scratch the row-walker kernel wants for its per-block partial tiles (bf16, 3x3, W % 32 == 0) ...
     int64_t need = (dtype == SP_BF16 && ksize == 3 && sp_tune(SP_TUNE_WGRAD_ROWS, 1)) ? (int64_t)sp_wgrad_rows_workspace(n, h, w_, cin_p, cout) : 0;
+    // ... the per-split slabs of the streaming 1x1 kernel ...
+    if (dtype == SP_BF16 && ksize == 1) {
+        const int64_t s1 = sp_wgrad1x1_workspace(n, h, w_, cin_p, cout, (cout + 7) & ~7);
+        if (s1 > need) need = s1;
+    }
     // ... and, in the deterministic mode, the per-split slabs of the per-tap kernels for every other shape
     if (sp_deterministic(dtype)) {
         const int64_t slab = dtype == SP_F32 ? pertap_slab_floats<float>(n, h, w_, cin_p, cout, ksize) : pertap_slab_floats<bf16>(n, h, w_, cin_p, cout, ksize);

@@ -1,0 +1,287 @@
+// Weight gradient of the 1x1 convolutions (bf16): dW[co][ci] = sum_p dY[p][co] * X[p][ci], a GEMM whose reduction runs over
+// ALL pixels (20 k .. 1.3 M at batch 20) into at most 768 x 768 outputs - the operands are read once and the arithmetic is
+// negligible, so the layer is a streaming reduction bound by HBM (64 -> 128 @64^2: 31 MB, ~4 us at 8 TB/s).  The per-tap
+// kernel (conv_wgrad.hip) runs these layers as a thousand short-lived blocks (3-5 register-staged steps each) that meet through
+// fp32 atomics: 17 .. 59 us.  Here
+//   * a block owns a 64 co x 64 ci tile and a LONG pixel range, and streams it through a 4-slot LDS ring filled by LDS-DMA
+//     (buffer_load ... lds, 16 B per lane, rows exactly as they lie in HBM; lanes past the tensor / the channel count read an
+//     out-of-range offset = zeros): three 16 KB stages in flight per block, two blocks per CU;
+//   * the transpose the MFMA operands need (k = pixels) happens on the LDS read (ds_read_b64_tr_b16; 128-byte rows, the 32-byte
+//     column swizzled by (row >> 1) & 3 on the DMA's source side, as in the row-walking 3x3 kernel);
+//   * workgroups are numbered so that the tiles sharing a pixel range run on the same XCD (one L2 fetch of the rows);
+//   * the bias gradient (column sums of dY) rides on the MFMA pipe: one extra product per fragment row with an all-ones B;
+//   * pixel splits store their partial tile into their own slab with plain stores and a second kernel sums the slabs in a
+//     fixed order (16 slab groups per column block, LDS tree): no atomics, bit-identical run to run in every mode.
+#include <cstdint>
+#include <utility>
+#include "common.h"
+
+namespace {
+
+constexpr int W1_TILE = 64 * 128;          // 64 pixel rows x 64 channels x 2 B
+constexpr int W1_STAGE = 2 * W1_TILE;      // dY tile + X tile
+constexpr int W1_NST = 4;
+constexpr int W1_LDS = W1_NST * W1_STAGE;  // 64 KB
+
+struct W1Args {
+    const bf16* x;
+    const bf16* dy;
+    float* dw;
+    float* dbias;
+    float* slabs;          // [nsplit][n_dw] partial dW (nullptr: a single split adds to dW itself)
+    float* bias_slabs;     // [nsplit][bias_ld]
+    long M, n_dw;
+    int CIN, COUT, LD_DY, tiles, ci_tiles, stages_per_split, nsplit, bias_ld;
+};
+
+template <int N> __device__ __forceinline__ void w1_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int OFF> __device__ __forceinline__ void w1_tr(uint2& d, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "i"(OFF));
+}
+__device__ __forceinline__ bf16x8_t w1_frag(const uint2& lo, const uint2& hi) {
+    return __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad1x1_stream_kernel(W1Args a) {
+    extern __shared__ __attribute__((aligned(16))) char w1_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wa = wave >> 1, wb = wave & 1;
+    // consecutive workgroups go to consecutive XCDs (8, each with its own L2): the tiles of one pixel split - which read the
+    // same dY / X rows - are dealt to the SAME XCD, the splits round-robin over the XCDs
+    // (layers with fewer than 8 splits keep the plain numbering: their tiles are what fills the chip)
+    int split, tile;
+    if (a.nsplit >= 8) {
+        const int xcd = (int)blockIdx.x & 7, q = (int)blockIdx.x >> 3;
+        split = (q / a.tiles) * 8 + xcd;
+        tile = q % a.tiles;
+        if (split >= a.nsplit) return;
+    } else {
+        split = (int)blockIdx.x / a.tiles;
+        tile = (int)blockIdx.x % a.tiles;
+    }
+    const int co0 = (tile / a.ci_tiles) * 64, ci0 = (tile % a.ci_tiles) * 64;
+    const long total_stages = (a.M + 63) / 64;
+    const long st0 = (long)split * a.stages_per_split;
+    const int nk = (int)(total_stages - st0 < a.stages_per_split ? total_stages - st0 : a.stages_per_split);
+    if (nk <= 0) return;                                                   // (the plan gives every split at least one stage)
+    const unsigned lds_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)w1_smem);
+
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.x), 0, (int)(a.M * a.CIN * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.dy), 0, (int)(a.M * a.LD_DY * 2), 0x00020000);
+    // ---- DMA side: lane l of a wave instruction writes pixel row (l >> 3), physical 16-byte slot (l & 7) of an 8-row group;
+    // the 32-byte column is swizzled by key = (row >> 1) & 3 = (l >> 4) & 3 (8 | first row of the group)
+    const int dpx = lane >> 3;
+    const int dls = ((((lane & 7) >> 1) ^ ((dpx >> 1) & 3)) << 1) | (lane & 1);      // logical 16-byte slot this lane fetches
+    const bool y_ok = co0 + dls * 8 < a.LD_DY;
+    const bool x_ok = ci0 + dls * 8 < a.CIN;
+    const unsigned y_lane = (unsigned)((dpx * a.LD_DY + co0 + dls * 8) * 2);
+    const unsigned x_lane = (unsigned)((dpx * a.CIN + ci0 + dls * 8) * 2);
+    auto issue = [&](int ks) {
+        const long pb = (st0 + ks) * 64;
+        char* sb = w1_smem + (ks & (W1_NST - 1)) * W1_STAGE;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int grp = wave + 4 * q;                                  // 8-row group of the 64-pixel stage
+            const long row0 = pb + grp * 8;
+            const bool in = row0 + dpx < a.M;
+            const unsigned yo = (in && y_ok) ? (unsigned)(row0 * a.LD_DY * 2) + y_lane : OOB;
+            const unsigned xo = (in && x_ok) ? (unsigned)(row0 * a.CIN * 2) + x_lane : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(y_rsrc, (__attribute__((address_space(3))) void*)(sb + grp * 1024), 16, (int)yo, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (__attribute__((address_space(3))) void*)(sb + W1_TILE + grp * 1024), 16, (int)xo, 0, 0, 0);
+        }
+    };
+    // ---- fragment reads: a 16-lane group reads [4 pixels][16 channels]; lane group g takes pixels {g*4 .. g*4+3} (+16 for the
+    // second read), the same permutation of the reduction index for both operands
+    const int i16 = lane & 15, g = lane >> 4;
+    const int row1 = g * 4 + (i16 >> 2);
+    const int key = (row1 >> 1) & 3;
+    unsigned fa[2], fb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        fa[i] = lds_base + (unsigned)(row1 * 128 + (((wa * 2 + i) ^ key) * 32) + (i16 & 3) * 8);
+        fb[i] = lds_base + (unsigned)(W1_TILE + row1 * 128 + (((wb * 2 + i) ^ key) * 32) + (i16 & 3) * 8);
+    }
+    const bool do_bias = a.dbias != nullptr && ci0 == 0 && wb == 0;       // wave-uniform
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
+    f32x4_t acc[2][2], accb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        accb[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+
+    issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 2) issue(2);
+    for (int ks = 0; ks < nk; ++ks) {
+        // own loads of stage ks landed (4 instructions per stage; up to two later stages stay in flight) ...
+        if (ks + 2 < nk) w1_wait_vmcnt<8>();
+        else if (ks + 1 < nk) w1_wait_vmcnt<4>();
+        else w1_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();                                      // ... everybody's did, and everybody left stage ks - 1
+        if (ks + 3 < nk) issue(ks + 3);                                    // into the slot stage ks - 1 occupied
+        const unsigned sb = (unsigned)((ks & (W1_NST - 1)) * W1_STAGE);
+        uint2 al[2][2], ah[2][2], bl[2][2], bh[2][2];                      // [32-pixel half][fragment]
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            w1_tr<0>(al[0][i], sb + fa[i]);     w1_tr<2048>(ah[0][i], sb + fa[i]);
+            w1_tr<4096>(al[1][i], sb + fa[i]);  w1_tr<6144>(ah[1][i], sb + fa[i]);
+            w1_tr<0>(bl[0][i], sb + fb[i]);     w1_tr<2048>(bh[0][i], sb + fb[i]);
+            w1_tr<4096>(bl[1][i], sb + fb[i]);  w1_tr<6144>(bh[1][i], sb + fb[i]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bf16x8_t av = w1_frag(al[kk][i], ah[kk][i]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w1_frag(bl[kk][j], bh[kk][j]), acc[i][j], 0, 0, 0);
+                if (do_bias) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, ones, accb[i], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- partial tile -> this split's slab (plain stores), or straight onto dW when the layer has a single split
+    const bool direct = a.slabs == nullptr;
+    float* out = direct ? a.dw : a.slabs + (long)split * a.n_dw;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + (wa * 2 + i) * 16 + g * 4 + r;
+            if (co >= a.COUT) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int ci = ci0 + (wb * 2 + j) * 16 + i16;
+                if (ci >= a.CIN) continue;
+                const long o = (long)co * a.CIN + ci;
+                if (direct) out[o] += acc[i][j][r]; else out[o] = acc[i][j][r];
+            }
+            if (do_bias && i16 == 0) {
+                if (direct) a.dbias[co] += accb[i][r]; else a.bias_slabs[(long)split * a.bias_ld + co] = accb[i][r];
+            }
+        }
+}
+
+// out[e] += sum_s slab[s][e] for the dW columns and then the bias columns.  A block owns 16 float4 columns; its 16 thread rows
+// take the slabs s = g, g + 16, ... (independent loads) and meet in LDS in a fixed order.
+__global__ __launch_bounds__(256) void wgrad1x1_reduce_kernel(const float* __restrict__ slabs, int nsplit, long n_dw, float* __restrict__ dw,
+                                                              const float* __restrict__ bias_slabs, int bias_ld, int cout,
+                                                              float* __restrict__ dbias) {
+    __shared__ float4 red[16][16];
+    const int c16 = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const long cols4 = n_dw / 4;
+    const long bias4 = bias_slabs != nullptr ? bias_ld / 4 : 0;
+    const long c = (long)blockIdx.x * 16 + c16;
+    const float* src = nullptr;
+    long stride = 0;
+    if (c < cols4) { src = slabs + c * 4; stride = n_dw; }
+    else if (c < cols4 + bias4) { src = bias_slabs + (c - cols4) * 4; stride = bias_ld; }
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (src != nullptr) {
+#pragma unroll 4
+        for (int k = g; k < nsplit; k += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (long)k * stride);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    red[g][c16] = s;
+    __syncthreads();
+    if (g != 0 || src == nullptr) return;
+    float4 t = red[0][c16];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) { const float4 v = red[k][c16]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+    if (c < cols4) {
+        float4 d = *reinterpret_cast<float4*>(dw + c * 4);
+        d.x += t.x; d.y += t.y; d.z += t.z; d.w += t.w;
+        *reinterpret_cast<float4*>(dw + c * 4) = d;
+    } else {
+        const int co = (int)(c - cols4) * 4;
+        const float v[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (co + r < cout) dbias[co + r] += v[r];
+    }
+}
+
+struct W1Plan { int tiles, ci_tiles, nsplit, stages_per_split; bool ok; };
+
+W1Plan w1_plan(int n, int h, int w, int cin, int cout, int ld_dy) {
+    W1Plan p;
+    p.ok = false;
+    const int target = sp_tune(SP_TUNE_WGRAD1X1, 256);
+    const long M = (long)n * h * w;
+    p.ci_tiles = (cin + 63) / 64;
+    p.tiles = p.ci_tiles * ((cout + 63) / 64);
+    p.nsplit = 1;
+    p.stages_per_split = 1;
+    if (target <= 0 || cin % 8 != 0 || ld_dy % 8 != 0) return p;
+    if (M * cin * 2 >= (1L << 31) || M * ld_dy * 2 >= (1L << 31)) return p;           // 32-bit buffer offsets
+    const long stages = (M + 63) / 64;
+    // ~target blocks (one per CU measured best: 128 / 192 / 256 / 384 / 512 -> 0.250 / 0.211 / 0.189 / 0.201 / 0.197 ms over the step's
+    // fourteen shapes - more splits mean more slab traffic), at least four 64-pixel stages per split
+    long nsplit = (target + p.tiles - 1) / p.tiles;
+    if (nsplit > stages / 4) nsplit = stages / 4;
+    if (nsplit < 1) nsplit = 1;
+    const long sps = (stages + nsplit - 1) / nsplit;
+    p.stages_per_split = (int)sps;
+    p.nsplit = (int)((stages + sps - 1) / sps);
+    p.ok = true;
+    return p;
+}
+
+}  // namespace
+
+long sp_wgrad1x1_workspace(int n, int h, int w, int cin, int cout, int ld_dy) {
+    const W1Plan p = w1_plan(n, h, w, cin, cout, ld_dy);
+    if (!p.ok || p.nsplit <= 1) return 0;
+    return (long)p.nsplit * ((long)cout * cin + ((cout + 3) & ~3));
+}
+
+// SP_OK after launching, 1 if the layer is not covered (the caller falls back to the per-tap kernel)
+int sp_wgrad1x1_launch(const void* x, const void* dy, float* dw, float* dbias, int n, int h, int w, int cin, int cout, int ld_dy,
+                       float* ws, long ws_floats, hipStream_t s) {
+    const W1Plan p = w1_plan(n, h, w, cin, cout, ld_dy);
+    if (!p.ok) return 1;
+    W1Args a;
+    a.x = reinterpret_cast<const bf16*>(x);
+    a.dy = reinterpret_cast<const bf16*>(dy);
+    a.dw = dw;
+    a.dbias = dbias;
+    a.M = (long)n * h * w;
+    a.n_dw = (long)cout * cin;
+    a.CIN = cin; a.COUT = cout; a.LD_DY = ld_dy;
+    a.ci_tiles = p.ci_tiles;
+    a.tiles = p.tiles;
+    a.stages_per_split = p.stages_per_split;
+    a.nsplit = p.nsplit;
+    a.bias_ld = (cout + 3) & ~3;
+    a.slabs = nullptr;
+    a.bias_slabs = nullptr;
+    if (p.nsplit > 1) {
+        if (ws == nullptr || ws_floats < (long)p.nsplit * (a.n_dw + a.bias_ld)) return 1;
+        a.slabs = ws;
+        a.bias_slabs = dbias != nullptr ? ws + (long)p.nsplit * a.n_dw : nullptr;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad1x1_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W1_LDS);
+        if (e != hipSuccess) { sp_set_error("hipFuncSetAttribute(LDS=%d) failed: %s", W1_LDS, hipGetErrorString(e)); return SP_ERR_LAUNCH; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(wgrad1x1_stream_kernel, dim3((unsigned)(p.tiles * (p.nsplit >= 8 ? ((p.nsplit + 7) / 8) * 8 : p.nsplit))), dim3(256), W1_LDS, s, a);
+    SP_LAUNCH_CHECK();
+    if (p.nsplit > 1) {
+        const long cols = a.n_dw / 4 + (a.bias_slabs != nullptr ? a.bias_ld / 4 : 0);
+        hipLaunchKernelGGL(wgrad1x1_reduce_kernel, dim3((unsigned)((cols + 15) / 16)), dim3(256), 0, s, a.slabs, p.nsplit, a.n_dw, dw, a.bias_slabs,
+                           a.bias_ld, cout, dbias);
+        SP_LAUNCH_CHECK();
+    }
+    return SP_OK;
+}

@@ -214,6 +214,31 @@ def test_conv1x1_splitk_matches_direct_kernel_with_residuals():
     assert float((y_split - y_direct).abs().max()) <= 2 ** -7 * float(y_direct.abs().max())
 
 
+WGRAD_1X1_CASES = [(72, 128, 1, 3, 41, 24), (64, 136, 1, 2, 32, 48), (8, 64, 1, 20, 128, 128), (64, 3, 1, 20, 128, 128), (128, 256, 1, 20, 32, 32),
+                   (256, 32, 1, 20, 16, 16)]
+
+
+@pytest.mark.parametrize("case", WGRAD_1X1_CASES)
+def test_conv1x1_streaming_weight_gradient_bf16(case):
+    """wgrad1x1_stream_kernel (conv_wgrad_1x1.hip): long pixel ranges per block, LDS-DMA ring, transposed LDS reads, slabs + ordered
+    reduce.  Ragged pixel counts (a partial last 64-pixel stage, 9 splits on 8 XCDs), partial channel tiles (Cin 72 / 8, Cout 136 / 3)
+    and the step's own shapes; the weight and bias gradients of two runs are bit-identical (no atomics)."""
+    test_sn_conv_forward_backward(case, torch.bfloat16)
+    cin, cout, k, n, h, w = case
+    ops.set_compute_dtype(torch.bfloat16)
+    m = models.SNConv2d(cin, cout, k).cuda()
+    synth(m, 7, "c.")
+    x = dev(rnd(n, cin, h, w, seed=2), torch.bfloat16)
+    gy = dev(rnd(n, cout, h, w, seed=3), torch.bfloat16)
+    grads = []
+    for _ in range(2):
+        m.zero_grad(set_to_none=True)
+        synth(m, 7, "c.")                       # same u / v: the power iteration of the first run must not leak into the second
+        m(x).backward(gy)
+        grads.append((m.weight_orig.grad.clone(), m.bias.grad.clone()))
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+
+
 POOL2_CASES = [(64, 64, 2, 16, 32, 0), (64, 64, 2, 8, 32, 0), (64, 128, 2, 16, 32, 0), (128, 128, 3, 8, 64, 0), (40, 256, 1, 16, 32, 0),
                (64, 128, 2, 16, 32, 2), (64, 64, 5, 64, 128, 0), (64, 128, 5, 64, 128, 2)]
 
