@@ -43,7 +43,8 @@ int sp_version(void);
  * built-in default.  Except SP_TUNE_DETERMINISTIC none of them changes results beyond fp summation order.
  *   SP_TUNE_CONV_TALL        0 = never use conv3x3_tall_kernel, 1 = where its tiles fill the chip (default), 2 / 3 = force the 16- / 8-row form
  *   SP_TUNE_IGEMM_DMA        0 = never use the LDS-DMA igemm kernel, 1 = small-spatial 3x3 layers (default), 2 = everywhere
- *   SP_TUNE_WGRAD_ROWS       0 = never use the row-walker 3x3 weight-gradient kernel, 1 = wherever legal (default)
+ *   SP_TUNE_WGRAD_ROWS       0 = never use the row-walker 3x3 weight-gradient kernel, 1 = maps >= 32 wide and 16 x 16 maps (default),
+ *                            2 = maps >= 32 wide only, 3 = 8 x 8 maps too
  *   SP_TUNE_DETERMINISTIC    1 = every floating-point reduction runs in a fixed order (per-split partial slabs + ordered
  *                            reduce instead of fp32 atomics): bit-identical results run to run; 0 = atomics where they are
  *                            faster; default (-1): on for SP_F32 storage (the parity mode), off for SP_BF16

@@ -62,14 +62,20 @@ __device__ __forceinline__ bf16x8_t wr_frag(const uint2& lo, const uint2& hi) {
     return __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
 }
 
+// NW = 0: maps at least 32 pixels wide (column strips of an image).  NW = 16 / 8: NARROW maps - a "strip" is 32 / NW images side
+// by side: the dY row slot holds their rows back to back, the X row slot their halo rows (NW + 2 pixels each), so pixel p of
+// the strip finds its X neighbourhood at LDS row p + 2 * (p / NW) + tap column: the fragment reads only get a lane-dependent
+// base and their own address for the second half (the swizzle key of row + 16 + 2 * (16 / NW) differs from that of row).
+template <int NW>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_rows_kernel(WrArgs a) {
+    constexpr int G = NW ? 32 / NW : 1;
     extern __shared__ __attribute__((aligned(16))) char wr_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = a.H, W = a.W, CIN = a.CIN;
     const int co0 = (blockIdx.y / a.ci_tiles) * 64, ci0 = (blockIdx.y % a.ci_tiles) * 64;
     const int RU = a.rows_per_unit, SPU = RU / WR_R;
-    const int strips = W / 32, chunks = H / RU;
+    const int strips = NW ? 1 : W / 32, chunks = H / RU;
     const int my_units = (a.units - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int total_stages = my_units * SPU;
     if (total_stages <= 0) return;
@@ -96,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_rows_kernel(WrArgs a) {
         const int ch = u % chunks;
         const int t = u / chunks;
         x0 = (t % strips) * 32;
-        n = t / strips;
+        n = (t / strips) * G;                                                    // narrow: first image of the group
         y0 = ch * RU;
     };
     // X row `urow` (0 .. RU+1 <-> image row y0 - 1 + urow) of unit ui -> ring slot `slot`; returns instructions issued
@@ -108,9 +114,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_rows_kernel(WrArgs a) {
         for (int i = 0; i < 5; ++i) {
             if ((i & 3) == wave) {                                               // wave-uniform
                 const int px = i * 8 + dpx;
-                const int xx = x0 - 1 + px;
-                const bool ok = row_ok && x_ch_ok && px < 34 && (unsigned)xx < (unsigned)W;
-                const unsigned off = ok ? (unsigned)((((n * H + y) * W + xx) * CIN + ci0 + dls * 8) * 2) : OOB;
+                int img = n, xx = x0 - 1 + px;
+                bool ok = row_ok && x_ch_ok && px < 34;
+                if constexpr (NW != 0) {
+                    const int j = px / (NW + 2);                                 // image of the group, column inside its halo row
+                    img = n + j;
+                    xx = px - j * (NW + 2) - 1;
+                    ok = row_ok && x_ch_ok && j < G && img < a.N;
+                }
+                ok = ok && (unsigned)xx < (unsigned)W;
+                const unsigned off = ok ? (unsigned)((((img * H + y) * W + xx) * CIN + ci0 + dls * 8) * 2) : OOB;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, (int)off, 0, 0, 0);
                 ++cnt;
             }
@@ -119,8 +132,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_rows_kernel(WrArgs a) {
     };
     auto issue_y_row = [&](int n, int x0, int y, int slot) {
         char* dst = wr_smem + WR_XBYTES + slot * WR_YSLOT;
-        const int xx = x0 + wave * 8 + dpx;
-        const unsigned off = y_ch_ok ? (unsigned)((((n * HY + (y >> up)) * WY + (xx >> up)) * a.LD_DY + co0 + dls * 8) * 2) : OOB;
+        int img = n, xx = x0 + wave * 8 + dpx;
+        bool ok = y_ch_ok;
+        if constexpr (NW != 0) {
+            img = n + xx / NW;
+            xx &= NW - 1;
+            ok = ok && img < a.N;
+        }
+        const unsigned off = ok ? (unsigned)((((img * HY + (y >> up)) * WY + (xx >> up)) * a.LD_DY + co0 + dls * 8) * 2) : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(y_rsrc, (__attribute__((address_space(3))) void*)(dst + wave * 1024), 16, (int)off, 0, 0, 0);
         return 1;
     };
@@ -174,8 +193,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_rows_kernel(WrArgs a) {
     // split the pixel ROWS instead (row j of a stage pair goes to wave j & 3); their partial tiles meet in LDS at the end.
     const bool thin = a.thin_mode != 0 && CIN - ci0 <= 16;
     const int bcol = thin ? 0 : wave;
+    const int prow_x = NW ? prow + 2 * (prow / (NW ? NW : 1)) : prow;
+    [[maybe_unused]] unsigned b_offh[3];
 #pragma unroll
-    for (int ds = 0; ds < 3; ++ds) b_off[ds] = (unsigned)((prow + ds) * 128 + ((bcol ^ (((prow + ds) >> 1) & 3)) << 5) + (i16 & 3) * 8);
+    for (int ds = 0; ds < 3; ++ds) {
+        b_off[ds] = (unsigned)((prow_x + ds) * 128 + ((bcol ^ (((prow_x + ds) >> 1) & 3)) << 5) + (i16 & 3) * 8);
+        const int rh = prow_x + ds + 16 + (NW ? 2 * (16 / (NW ? NW : 1)) : 0);
+        b_offh[ds] = (unsigned)(rh * 128 + ((bcol ^ ((rh >> 1) & 3)) << 5) + (i16 & 3) * 8);
+    }
+    auto tr_bhi = [&](uint2& d, unsigned base, int ds) {
+        if constexpr (NW != 0) wr_tr<0>(d, base + b_offh[ds]); else wr_tr<2048>(d, base + b_off[ds]);
+    };
 
     f32x4_t acc[9][4], accb[4];
 #pragma unroll
@@ -211,14 +239,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_rows_kernel(WrArgs a) {
             uint2 alo[4], ahi[4], blo[9], bhi[9];
 #pragma unroll
             for (int i = 0; i < 4; ++i) { wr_tr<0>(alo[i], ab + a_off[i]); wr_tr<2048>(ahi[i], ab + a_off[i]); }
-            wr_tr<0>(blo[0], bb[0] + b_off[0]); wr_tr<2048>(bhi[0], bb[0] + b_off[0]);
-            wr_tr<0>(blo[1], bb[0] + b_off[1]); wr_tr<2048>(bhi[1], bb[0] + b_off[1]);
+            wr_tr<0>(blo[0], bb[0] + b_off[0]); tr_bhi(bhi[0], bb[0], 0);
+            wr_tr<0>(blo[1], bb[0] + b_off[1]); tr_bhi(bhi[1], bb[0], 1);
             wr_static_for<9>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
                 if constexpr (t + 2 < 9) {
                     constexpr int t2 = t + 2;
                     wr_tr<0>(blo[t2], bb[t2 / 3] + b_off[t2 % 3]);
-                    wr_tr<2048>(bhi[t2], bb[t2 / 3] + b_off[t2 % 3]);
+                    tr_bhi(bhi[t2], bb[t2 / 3], t2 % 3);
                     wr_wait_lgkm<4>();
                 } else if constexpr (t + 1 < 9) {
                     wr_wait_lgkm<2>();
@@ -373,14 +401,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_reduce_kernel(const float
 }  // namespace
 
 // Returns SP_OK after launching, or 1 if the shape is not covered (caller falls back to the per-tap kernel).
+// narrow maps walk 2 (16 wide) or 4 (8 wide) images side by side.  16 x 16 maps gain (512 -> 512 at batch 20: 74.9 -> 49.7 us);
+// 8 x 8 maps have too few rows per block to amortise the pipeline ramp (24.0 -> 29.3 us) and stay on the per-tap kernel unless
+// SP_TUNE_WGRAD_ROWS = 3; 2 keeps every narrow map on the per-tap kernel
+static int wr_narrow(int h, int w, int dy_up2) {
+    if (w % 32 == 0) return 0;
+    const int mode = sp_tune(SP_TUNE_WGRAD_ROWS, 1);
+    const bool covered = (w == 16 && mode != 2) || (w == 8 && mode == 3);
+    return (covered && h % WR_R == 0 && !dy_up2) ? w : -1;
+}
+
 long sp_wgrad_rows_workspace(int n, int h, int w, int cin, int cout) {
-    if (w % 32 != 0 || h % WR_R != 0) return 0;
+    if (wr_narrow(h, w, 0) < 0 || h % WR_R != 0) return 0;
     return 512L * (9 * 64 * 64 + 64);          // partial tiles + partial bias sums of at most 512 blocks
 }
 
 int sp_wgrad_rows_launch(const void* x, const void* dy, float* dw, float* dbias, int n, int h, int w, int cin, int cout,
                          int ld_dy, float* ws, long ws_floats, int dy_up2, hipStream_t s) {
-    if (w % 32 != 0 || h % WR_R != 0) return 1;
+    const int nw = wr_narrow(h, w, dy_up2);
+    if (nw < 0 || h % WR_R != 0) return 1;
+    const int strips = nw ? 1 : w / 32;                    // strips per image (wide maps) ...
+    const int groups = nw ? (n + 32 / nw - 1) / (32 / nw) : n;   // ... or images per strip (narrow maps)
     if ((long)n * h * w * cin * 2 >= (1L << 30) || (long)n * h * w * ld_dy * 2 >= (1L << 30)) return 1;
     WrArgs a;
     a.x = reinterpret_cast<const bf16*>(x);
@@ -414,25 +455,30 @@ int sp_wgrad_rows_launch(const void* x, const void* dy, float* dw, float* dbias,
     int ru = h, best_cost = 1 << 30, nblk = 1;
     for (int r = h; r >= 8 || r == h; r /= 2) {
         if (r % WR_R != 0) break;
-        const long units = (long)n * (w / 32) * (h / r);
+        const long units = (long)groups * strips * (h / r);
         const long k = (units + target - 1) / target;
         const long cost = k * (r + 1);                     // + 1: a mild preference for long chunks beyond exact ties
         if (cost < best_cost) { best_cost = (int)cost; ru = r; nblk = (int)((units + k - 1) / k); }
         if (r % 2 != 0 || r / 2 < 8) break;
     }
     a.rows_per_unit = ru;
-    a.units = n * (w / 32) * (h / ru);
+    a.units = groups * strips * (h / ru);
     // the slab area holds 512 partial tiles; the deterministic mode must not fall back to atomics with several blocks per pair
     if (det && (long)nblk * pairs > 512) nblk = 512 / pairs > 0 ? 512 / pairs : 1;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WR_LDS);
-        if (e != hipSuccess) { sp_set_error("hipFuncSetAttribute(LDS=%d) failed: %s", WR_LDS, hipGetErrorString(e)); return SP_ERR_LAUNCH; }
+        for (const void* k : {reinterpret_cast<const void*>(conv_wgrad_rows_kernel<0>), reinterpret_cast<const void*>(conv_wgrad_rows_kernel<16>),
+                              reinterpret_cast<const void*>(conv_wgrad_rows_kernel<8>)}) {
+            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, WR_LDS);
+            if (e != hipSuccess) { sp_set_error("hipFuncSetAttribute(LDS=%d) failed: %s", WR_LDS, hipGetErrorString(e)); return SP_ERR_LAUNCH; }
+        }
         attr_set = true;
     }
     a.slabs = use_slabs && (long)nblk * pairs <= 512 ? ws : nullptr;
     a.bias_part = (a.slabs != nullptr && dbias != nullptr) ? ws + 512L * 9 * 64 * 64 : nullptr;
-    hipLaunchKernelGGL(conv_wgrad_rows_kernel, dim3((unsigned)nblk, (unsigned)pairs), dim3(256), WR_LDS, s, a);
+    if (nw == 16) hipLaunchKernelGGL(conv_wgrad_rows_kernel<16>, dim3((unsigned)nblk, (unsigned)pairs), dim3(256), WR_LDS, s, a);
+    else if (nw == 8) hipLaunchKernelGGL(conv_wgrad_rows_kernel<8>, dim3((unsigned)nblk, (unsigned)pairs), dim3(256), WR_LDS, s, a);
+    else hipLaunchKernelGGL(conv_wgrad_rows_kernel<0>, dim3((unsigned)nblk, (unsigned)pairs), dim3(256), WR_LDS, s, a);
     if (a.slabs != nullptr) {
         int z = 512 / (36 * pairs);                       // ~512 reducer blocks
         if (z > nblk / 4) z = nblk / 4;

@@ -182,6 +182,17 @@ def test_conv_epilogue_act_and_residuals(dtype):
     close(m.weight_orig.grad, S["c.weight_orig"].grad, 2 * tol, "dW")
 
 
+@pytest.mark.parametrize("case", [(128, 256, 3, 2, 8, 8), (520, 128, 3, 1, 8, 8), (64, 72, 3, 5, 8, 8), (512, 512, 3, 20, 8, 8), (72, 64, 3, 3, 16, 16)])
+def test_wgrad_row_walker_narrow_maps_bf16(case):
+    """Row-walking weight-gradient kernel on narrow maps (several images side by side in one 32-pixel strip): 8 x 8 maps are off
+    by default (tuning value 3 enables them), 16 x 16 maps with an odd image count (a half-empty last strip) ride along."""
+    ops.set_tuning(ops.TUNE_WGRAD_ROWS, 3)
+    try:
+        test_sn_conv_forward_backward(case, torch.bfloat16)
+    finally:
+        ops.set_tuning(ops.TUNE_WGRAD_ROWS, -1)
+
+
 SPLITK_1X1_CASES = [(768, 512, 1, 20, 2, 2), (512, 512, 1, 20, 4, 4), (256, 256, 1, 20, 8, 8), (520, 136, 1, 1, 5, 7), (256, 30, 1, 1, 6, 6),
                     (128, 64, 1, 3, 3, 3), (512, 768, 1, 2, 2, 2)]
 
