@@ -1436,9 +1436,115 @@ int launch_1x1_splitk(const sp_conv_params& p, hipStream_t s) {
     return SP_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// 3x3 convolution of an 8-channel input (bf16): the RGB images, padded 3 -> 8, entering the discriminator and the VGG-16
+// (64 outputs, 256 x 256, batch 20: 1.3 M pixels).  The generic kernels spend one K-step of 32 channels per tap on these 8
+// channels - nine MFMAs of which three quarters multiply zero padding - and are MFMA-bound at 73 us where HBM needs 24 us
+// (21 MB in, 168 MB out).  Here one pixel's 8 channels are exactly the 8 k-values ONE lane feeds a 16x16x32 MFMA, so the four
+// lane groups of a wave take FOUR TAPS of the same pixel: K = 9 taps x 8 channels is covered by three MFMAs.
+//   * a block owns 16 rows x 32 pixels; the 18 x 34 halo (16 B per pixel, 9.6 KB) is staged in LDS with zero borders;
+//   * lane (px, g) reads for MFMA m the pixel shifted by tap m * 4 + g: one ds_read_b128 at a lane-dependent offset;
+//   * the weights [co][tap][8] lie in fragment order already: 12 x 16-byte loads per lane, once, kept in registers;
+//   * a wave computes 64 channels x 32 pixels per row (fragment rows permuted: 16 consecutive channels per lane, 32-byte stores).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int C8_TH = 16, C8_TW = 32, C8_HW = C8_TW + 2, C8_HH = C8_TH + 2;
+
+__global__ __launch_bounds__(256) void conv3x3_cin8_kernel(sp_conv_params p) {
+    __shared__ __attribute__((aligned(16))) uint4 halo[C8_HH * C8_HW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = p.h, W = p.w_;
+    const int tiles_x = W / C8_TW, tiles_y = H / C8_TH;
+    int t = blockIdx.x;
+    const int tx0 = (t % tiles_x) * C8_TW; t /= tiles_x;
+    const int ty0 = (t % tiles_y) * C8_TH;
+    const int n = t / tiles_y;
+    const uint4* __restrict__ xg = reinterpret_cast<const uint4*>(p.x);
+    const uint4* __restrict__ wg = reinterpret_cast<const uint4*>(p.w);
+    // ---- halo tile (rows ty0 - 1 .. ty0 + 16, columns tx0 - 1 .. tx0 + 32), zero outside the image
+    uint4 hv[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int e = tid + q * 256;
+        const int r = e / C8_HW, c = e - r * C8_HW;
+        const int y = ty0 - 1 + r, x = tx0 - 1 + c;
+        hv[q] = make_uint4(0, 0, 0, 0);
+        if (e < C8_HH * C8_HW && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) hv[q] = xg[((long)n * H + y) * W + x];
+    }
+    // ---- weights: fragment i, MFMA m: row co = (i16 >> 2) * 16 + i * 4 + (i16 & 3), k-group g = tap m * 4 + g
+    const int i16 = lane & 15, g = lane >> 4;
+    uint4 a[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int co = (i16 >> 2) * 16 + i * 4 + (i16 & 3);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const int tap = m * 4 + g;
+            a[i][m] = make_uint4(0, 0, 0, 0);
+            if (tap < 9 && co < p.cout) a[i][m] = wg[co * 9 + tap];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int e = tid + q * 256;
+        if (e < C8_HH * C8_HW) halo[e] = hv[q];
+    }
+    __syncthreads();
+    // lane's three pixel offsets (in halo pixels, relative to (row, column) of the output pixel); taps 9..11 re-read tap 8
+    int toff[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        const int tap = m * 4 + g < 9 ? m * 4 + g : 8;
+        toff[m] = (tap / 3) * C8_HW + tap % 3;
+    }
+    const int co_b = g * 16;
+    const bool co_ok = co_b + 16 <= p.cout;
+    float bias[16];                                                            // the lane's 16 channels, once
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias[r] = 0.f;
+    if (p.bias && co_ok) Wide16<float>::ld(p.bias + co_b, bias);
+#pragma unroll 2
+    for (int rr = 0; rr < C8_TH / 4; ++rr) {
+        const int row = wave * (C8_TH / 4) + rr;                              // output row of the tile
+        f32x4_t acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc[i][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const uint4 b0 = halo[row * C8_HW + i16 + toff[m]];
+            const uint4 b1 = halo[row * C8_HW + 16 + i16 + toff[m]];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[i][m]), __builtin_bit_cast(bf16x8_t, b0), acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[i][m]), __builtin_bit_cast(bf16x8_t, b1), acc[i][1], 0, 0, 0);
+            }
+        }
+        if (!co_ok) continue;
+        const long pix0 = ((long)n * H + ty0 + row) * W + tx0 + i16;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r] + bias[i * 4 + r];
+            conv_epilogue16<bf16>(p, v, pix0 + j * 16, co_b, false);
+        }
+    }
+}
+
+int launch_cin8(const sp_conv_params& p, hipStream_t s) {
+    const long blocks = (long)p.n * (p.h / C8_TH) * (p.w_ / C8_TW);
+    hipLaunchKernelGGL(conv3x3_cin8_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
 template <typename T>
 int dispatch(const sp_conv_params& p, hipStream_t s) {
     const long M = (long)p.n * p.h * p.w_;
+    if (sizeof(T) == 2 && p.ksize == 3 && p.cin_p == 8 && p.cout % 16 == 0 && p.cout <= 64 && (p.ldy & 7) == 0 && !p.pool2 && !p.in_up2 &&
+        p.h % C8_TH == 0 && p.w_ % C8_TW == 0 && sp_tune(SP_TUNE_CONV_CIN8, 1) && sp_tune(SP_TUNE_CONV_TALL, 1) <= 1)   // (forced tall modes: tests)
+        return launch_cin8(p, s);
     if (sizeof(T) == 2 && p.ksize == 1 && p.cin_p <= 1024) {
         // small maps: K split over the waves of a block, as long as the blocks (32 pixels x 64 channels each, every one
         // streaming its whole 64 x Cin weight tile from L2) stay few: beyond ~320 the LDS-staged tile of the direct kernel wins
