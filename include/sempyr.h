@@ -59,12 +59,14 @@ int sp_version(void);
  *                            this many (32-pixel x 64-channel) blocks (default 320: the 2x2 .. 8x8 maps at batch 20; 0 = never)
  *   SP_TUNE_WGRAD1X1         block target of the streaming weight-gradient kernel of the bf16 1x1 layers (default 256; 0 = those
  *                            layers stay on the per-tap kernel)
- *   SP_TUNE_CONV_CIN8        0 = the 3x3 layers with an 8-channel input (the padded RGB images) stay on the generic kernels (default 1) */
+ *   SP_TUNE_CONV_CIN8        0 = the 3x3 layers with an 8-channel input (the padded RGB images) stay on the generic kernels (default 1)
+ *   SP_TUNE_CONV_THINCO      0 = the 3x3 layers with at most 4 output channels (input gradients towards the images) stay on the
+ *                            generic kernels (default 1) */
 enum { SP_TUNE_CONV_TALL = 0, SP_TUNE_IGEMM_DMA = 1, SP_TUNE_WGRAD_ROWS = 2, SP_TUNE_DETERMINISTIC = 3,
        SP_TUNE_SPLITK_TARGET = 4, SP_TUNE_SPLITK_MINSTEPS = 5, SP_TUNE_CONV1X1_DIRECT = 6, SP_TUNE_CONV_SHORT = 7,
        SP_TUNE_WGRAD9_BLOCKS = 8, SP_TUNE_WGRAD_BLOCKS = 9, SP_TUNE_WGRAD_MINSTEPS = 10, SP_TUNE_WGRAD_SMALL_M = 11,
        SP_TUNE_WGRAD_K1_TILE64 = 12, SP_TUNE_WGRAD_ROWS_THIN = 13, SP_TUNE_WGRAD_ROWS_BLOCKS = 14, SP_TUNE_WGRAD_ROWS_SLABS = 15,
-       SP_TUNE_CONV_STAGGER = 16, SP_TUNE_CONV1X1_SPLITK = 17, SP_TUNE_WGRAD1X1 = 18, SP_TUNE_CONV_CIN8 = 19, SP_TUNE_COUNT = 20 };
+       SP_TUNE_CONV_STAGGER = 16, SP_TUNE_CONV1X1_SPLITK = 17, SP_TUNE_WGRAD1X1 = 18, SP_TUNE_CONV_CIN8 = 19, SP_TUNE_CONV_THINCO = 20, SP_TUNE_COUNT = 21 };
 int sp_set_tuning(int32_t key, int32_t value);
 const char* sp_last_error_string(void);
 

@@ -7,7 +7,7 @@ from semantic_pyramid_for_image_generation_amd import ops, _lib as L
 B = 20
 dt = torch.bfloat16
 SHAPES = [(64, 64, 256), (128, 128, 128), (256, 256, 64), (512, 512, 32), (64, 128, 128), (128, 256, 64), (256, 512, 32), (256, 256, 32),
-          (512, 512, 16), (8, 64, 256)]
+          (512, 512, 16), (8, 64, 256), (64, 3, 256)]
 def timeit(fn, iters=20):
     for _ in range(3): fn()
     torch.cuda.synchronize()

@@ -1539,9 +1539,107 @@ int launch_cin8(const sp_conv_params& p, hipStream_t s) {
     return SP_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// 3x3 convolution with at most 4 output channels on a big map (bf16): the input gradients of the layers that read the RGB
+// images (64 -> 3 @256^2: 168 MB in, 21 MB out, ~24 us of HBM time).  The 64-channel tile of the tall kernel multiplies 61
+// idle rows (108 us, MFMA-bound); here a wave's MFMA carries ONE 16-row fragment (rows 0 .. Cout-1 live), so the layer costs
+// 18 MFMAs per 16 pixels and is bound by the input stream.
+//   * a block owns 8 rows x 32 pixels (three blocks per CU overlap each other's load and multiply phases; a persistent form that
+//     prefetched the next tile into registers needed 243 VGPRs, lost the third block and measured 76 instead of 62 us): the
+//     10 x 34 halo goes to LDS [pixel][Cin] with a pitch of Cin * 2 + 16 bytes (the 16
+//     lanes of a fragment read 16 consecutive pixels: conflict-free), zero outside the image;
+//   * the weights [co][tap][ci] are fragment-ordered: 9 * Cin / 32 loads of 16 bytes per lane, once, kept in registers;
+//   * lanes of group 0 hold (pixel, co = 0 .. 3): generic scalar epilogue (bias, mask, residuals, activation).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int TN_TH = 8, TN_TW = 32, TN_HW = TN_TW + 2, TN_HH = TN_TH + 2;
+
+template <int KC>                                                             // Cin / 32
+__global__ __launch_bounds__(256) void conv3x3_thinco_kernel(sp_conv_params p) {
+    extern __shared__ __attribute__((aligned(16))) char tn_smem[];
+    constexpr int CIN = KC * 32, PITCH = CIN * 2 + 16, CPP = KC * 4;           // 16-byte chunks per pixel
+    constexpr int NCH = TN_HH * TN_HW * CPP, PER = (NCH + 255) / 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = p.h, W = p.w_;
+    const int tiles_x = W / TN_TW, tiles_y = H / TN_TH;
+    int t = blockIdx.x;
+    const int tx0 = (t % tiles_x) * TN_TW; t /= tiles_x;
+    const int ty0 = (t % tiles_y) * TN_TH;
+    const int n = t / tiles_y;
+    const uint4* __restrict__ xg = reinterpret_cast<const uint4*>(p.x);
+    const uint4* __restrict__ wg = reinterpret_cast<const uint4*>(p.w);
+    uint4 hv[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int e = tid + q * 256;
+        const int px = e / CPP, c = e - px * CPP;
+        const int r = px / TN_HW, cc = px - r * TN_HW;
+        const int y = ty0 - 1 + r, x = tx0 - 1 + cc;
+        hv[q] = make_uint4(0, 0, 0, 0);
+        if (e < NCH && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) hv[q] = xg[(((long)n * H + y) * W + x) * CPP + c];
+    }
+    const int i16 = lane & 15, g = lane >> 4;
+    uint4 a[9][KC];                                                            // row i16 = output channel (zero rows past Cout)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            a[tap][kc] = make_uint4(0, 0, 0, 0);
+            if (i16 < p.cout) a[tap][kc] = wg[(i16 * 9 + tap) * CPP + kc * 4 + g];
+        }
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int e = tid + q * 256;
+        const int px = e / CPP, c = e - px * CPP;
+        if (e < NCH) *reinterpret_cast<uint4*>(tn_smem + px * PITCH + c * 16) = hv[q];
+    }
+    __syncthreads();
+    const bool vec_ok = ((p.ldy & 3) == 0) && ((p.cout & 3) == 0);
+#pragma unroll
+    for (int rr = 0; rr < TN_TH / 4; ++rr) {
+        const int row = wave * (TN_TH / 4) + rr;
+        f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const char* base = tn_smem + ((row + tap / 3) * TN_HW + i16 + tap % 3) * PITCH + g * 16;
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                const uint4 b0 = *reinterpret_cast<const uint4*>(base + kc * 64);
+                const uint4 b1 = *reinterpret_cast<const uint4*>(base + 16 * PITCH + kc * 64);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[tap][kc]), __builtin_bit_cast(bf16x8_t, b0), acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[tap][kc]), __builtin_bit_cast(bf16x8_t, b1), acc[1], 0, 0, 0);
+            }
+        }
+        if (g != 0) continue;                                                  // rows 4 .. 15 of the fragment are idle
+        const long pix0 = ((long)n * H + ty0 + row) * W + tx0 + i16;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float v[4] = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
+            conv_epilogue4<bf16>(p, v, pix0 + j * 16, 0, vec_ok);
+        }
+    }
+}
+
+template <int KC>
+int launch_thinco(const sp_conv_params& p, hipStream_t s) {
+    constexpr int LDS = TN_HH * TN_HW * (KC * 64 + 16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_thinco_kernel<KC>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) { sp_set_error("hipFuncSetAttribute(LDS=%d) failed: %s", LDS, hipGetErrorString(e)); return SP_ERR_LAUNCH; }
+        attr_set = true;
+    }
+    const long blocks = (long)p.n * (p.h / TN_TH) * (p.w_ / TN_TW);
+    hipLaunchKernelGGL(conv3x3_thinco_kernel<KC>, dim3((unsigned)blocks), dim3(256), LDS, s, p);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
 template <typename T>
 int dispatch(const sp_conv_params& p, hipStream_t s) {
     const long M = (long)p.n * p.h * p.w_;
+    if (sizeof(T) == 2 && p.ksize == 3 && p.cout <= 4 && (p.cin_p == 32 || p.cin_p == 64) && !p.pool2 && !p.in_up2 && p.h % TN_TH == 0 &&
+        p.w_ % TN_TW == 0 && sp_tune(SP_TUNE_CONV_THINCO, 1) && sp_tune(SP_TUNE_CONV_TALL, 1) <= 1)
+        return p.cin_p == 64 ? launch_thinco<2>(p, s) : launch_thinco<1>(p, s);
     if (sizeof(T) == 2 && p.ksize == 3 && p.cin_p == 8 && p.cout % 16 == 0 && p.cout <= 64 && (p.ldy & 7) == 0 && !p.pool2 && !p.in_up2 &&
         p.h % C8_TH == 0 && p.w_ % C8_TW == 0 && sp_tune(SP_TUNE_CONV_CIN8, 1) && sp_tune(SP_TUNE_CONV_TALL, 1) <= 1)   // (forced tall modes: tests)
         return launch_cin8(p, s);

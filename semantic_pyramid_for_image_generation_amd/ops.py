@@ -483,7 +483,7 @@ def _is_halo128(n, h, w, cout, ksize) -> bool:
 
 
 TUNE_CONV_TALL, TUNE_IGEMM_DMA, TUNE_WGRAD_ROWS, TUNE_DETERMINISTIC = 0, 1, 2, 3
-TUNE_CONV1X1_SPLITK, TUNE_WGRAD1X1, TUNE_CONV_CIN8 = 17, 18, 19
+TUNE_CONV1X1_SPLITK, TUNE_WGRAD1X1, TUNE_CONV_CIN8, TUNE_CONV_THINCO = 17, 18, 19, 20
 _POOL2_BWD_FUSED = os.environ.get("SP_POOL2_BWD_FUSED", "1") == "1"     # A/B switch (profiles/README.md)
 
 
