@@ -2,34 +2,93 @@
 // per-layer forward-pre-hook of torch.nn.utils.spectral_norm (60 call sites):
 //   v <- normalize(W^T u);  u <- normalize(W v);  sigma = u . (W v);  W_sn = W / sigma
 // plus the re-layout of W_sn into the MFMA-friendly packings the convolution / linear kernels read.
-// Layers are described by a device-resident table (sp_sn_layer); grid.y indexes the layer, blocks
-// beyond a layer's extent exit immediately (ragged batch without a block map).
+// Layers are described by a device-resident table (sp_sn_layer); persistent blocks walk the work units of all layers
+// (sn_for_each_unit below).
 //
 // Per-call scratch (fp32, offsets from the table): t[cols] (becomes the v snapshot), s[rows] (= W v),
 // usnap[rows], scal[4] = {sigma, 1/sigma, -, -}; at part_off: ceil(rows/128) x cols partial sums of W^T u.  The snapshots are what the backward of THIS forward
 // needs: the discriminator runs 2-3 forwards (each with its own power iteration) before a backward.
+#include <type_traits>
 #include "common.h"
 
 namespace {
 
 constexpr float SN_EPS = 1e-12f;
 
+// Ragged batch over the layers of a network.  The first version used grid.y = layer with grid.x / grid.z sized for the LARGEST
+// layer and let the blocks past a layer's extent exit: 12 k - 57 k mostly empty workgroups per launch, whose dispatch alone
+// took longer than the useful work (rocprof: 27 + 27 + 41 + 66 us for ~10 us of memory traffic each).  Now a fixed grid of
+// persistent blocks walks the work units of all layers: every block builds the prefix of units per layer in LDS (one table
+// read per layer, in parallel) and finds the layer of a unit by bisection.
+constexpr int SN_MAX_LAYERS = 256, SN_GRID = 1024;
+template <typename Tab, typename UnitsOf, typename Body>
+__device__ __forceinline__ void sn_for_each_unit(const Tab* __restrict__ table, int n_layers, UnitsOf units_of, Body body) {
+    __shared__ int pre[SN_MAX_LAYERS + 1];
+    for (int l = threadIdx.x; l < n_layers; l += 256) pre[l + 1] = units_of(table[l]);
+    if (threadIdx.x == 0) pre[0] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int l = 1; l <= n_layers; ++l) pre[l] += pre[l - 1];
+    __syncthreads();
+    const int total = pre[n_layers];
+    for (int u = blockIdx.x; u < total; u += gridDim.x) {
+        int lo = 0, hi = n_layers - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (pre[mid] <= u) lo = mid; else hi = mid - 1;
+        }
+        body(table[lo], lo, u - pre[lo]);
+        __syncthreads();                                   // the bodies use block-wide LDS scratch
+    }
+}
+
 // phase 1a: part[z][c] = sum_{r in row slab z} W[r][c] * u[r]   (one 128-row slab per blockIdx.z; plain stores)
 constexpr int SN_SLAB = 128;
-__global__ __launch_bounds__(256) void sn_wtu_kernel(const sp_sn_layer* __restrict__ table, float* __restrict__ scratch) {
-    const sp_sn_layer L = table[blockIdx.y];
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    const int r0 = blockIdx.z * SN_SLAB;
-    if (blockIdx.x * 256 >= L.cols || r0 >= L.rows) return;
+__global__ __launch_bounds__(256) void sn_wtu_kernel(const sp_sn_layer* __restrict__ table, int n_layers, float* __restrict__ scratch) {
     __shared__ float us[SN_SLAB];
-    const int r1 = min(r0 + SN_SLAB, L.rows);
-    if (threadIdx.x < r1 - r0) us[threadIdx.x] = L.u[r0 + threadIdx.x];
-    __syncthreads();
-    if (c >= L.cols) return;
-    float acc = 0.f;
-    const float* w = L.w + (long)r0 * L.cols + c;
-    for (int r = 0; r < r1 - r0; ++r) acc += w[(long)r * L.cols] * us[r];
-    scratch[L.part_off + (long)blockIdx.z * L.cols + c] = acc;
+    __shared__ float4 red[4][64];
+    sn_for_each_unit(table, n_layers,
+        [](const sp_sn_layer& L) { return ((L.cols + 255) / 256) * ((L.rows + SN_SLAB - 1) / SN_SLAB); },
+        [&](const sp_sn_layer& L, int, int local) {
+            const int ncb = (L.cols + 255) / 256;
+            const int z = local / ncb, bx = local - z * ncb;
+            const int r0 = z * SN_SLAB, r1 = min(r0 + SN_SLAB, L.rows);
+            if (threadIdx.x < r1 - r0) us[threadIdx.x] = L.u[r0 + threadIdx.x];
+            __syncthreads();
+            if ((L.cols & 3) == 0) {
+                // four columns per lane (16-byte loads, a wave reads 1 KB of a row), the slab's rows dealt to the four waves in
+                // groups of 32: eight independent loads in flight per lane instead of one dependent chain of 128
+                const int q = threadIdx.x & 63, rg = threadIdx.x >> 6;
+                const int c4 = bx * 256 + q * 4;
+                float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c4 < L.cols) {
+                    const int ra = r0 + rg * 32, rb = min(ra + 32, r1);
+                    const float* w = L.w + (long)ra * L.cols + c4;
+#pragma unroll 8
+                    for (int r = 0; r < rb - ra; ++r) {
+                        const float4 v = *reinterpret_cast<const float4*>(w + (long)r * L.cols);
+                        const float uu = us[rg * 32 + r];
+                        a4.x += v.x * uu; a4.y += v.y * uu; a4.z += v.z * uu; a4.w += v.w * uu;
+                    }
+                }
+                red[rg][q] = a4;
+                __syncthreads();
+                if (rg == 0 && c4 < L.cols) {
+                    float4 t = red[0][q];
+#pragma unroll
+                    for (int k = 1; k < 4; ++k) { const float4 v = red[k][q]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+                    *reinterpret_cast<float4*>(scratch + L.part_off + (long)z * L.cols + c4) = t;
+                }
+                return;
+            }
+            const int c = bx * 256 + threadIdx.x;
+            if (c >= L.cols) return;
+            float acc = 0.f;
+            const float* w = L.w + (long)r0 * L.cols + c;
+#pragma unroll 8
+            for (int r = 0; r < r1 - r0; ++r) acc += w[(long)r * L.cols] * us[r];
+            scratch[L.part_off + (long)z * L.cols + c] = acc;
+        });
 }
 // phase 1b: t[c] = sum_z part[z][c] in slab order (the atomics this replaces made even the forward pass vary run to run)
 __global__ __launch_bounds__(256) void sn_tsum_kernel(const sp_sn_layer* __restrict__ table, float* __restrict__ scratch) {
@@ -45,32 +104,48 @@ __global__ __launch_bounds__(256) void sn_tsum_kernel(const sp_sn_layer* __restr
 
 // phase 2: one wave per row: s[r] = W[r] . v  with v = t / max(||t||, eps) (power iteration) or the
 // stored v (eval mode).  The wave accumulates ||t||^2 on the same pass.  Row 0's wave also writes v.
-__global__ __launch_bounds__(256) void sn_wv_kernel(const sp_sn_layer* __restrict__ table, float* __restrict__ scratch,
+__global__ __launch_bounds__(256) void sn_wv_kernel(const sp_sn_layer* __restrict__ table, int n_layers, float* __restrict__ scratch,
                                                     int power_iter) {
-    const sp_sn_layer L = table[blockIdx.y];
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (r >= L.rows) return;
-    float* t = scratch + L.scratch_off;
-    float* s = t + L.cols;
-    const float* vin = power_iter ? t : L.v;
-    const float* w = L.w + (long)r * L.cols;
-    float dot = 0.f, nn = 0.f;
-    for (int c = lane; c < L.cols; c += 64) {
-        const float tv = vin[c];
-        dot += w[c] * tv;
-        nn += tv * tv;
-    }
-    dot = wave_sum(dot);
-    nn = wave_sum(nn);
-    float inv = 1.f;
-    if (power_iter) inv = 1.f / fmaxf(sqrtf(nn), SN_EPS);
-    if (lane == 0) s[r] = dot * inv;
-    if (power_iter && r == 0) {
-        // v <- t/||t|| : persistent buffer now, snapshot (in place over t) by the pack kernel later would
-        // race with other rows still reading t, so only the persistent copy is written here.
-        for (int c = lane; c < L.cols; c += 64) L.v[c] = vin[c] * inv;
-    }
+    sn_for_each_unit(table, n_layers, [](const sp_sn_layer& L) { return (L.rows + 3) / 4; },
+        [&](const sp_sn_layer& L, int, int local) {
+            const int r = local * 4 + (threadIdx.x >> 6);
+            const int lane = threadIdx.x & 63;
+            if (r >= L.rows) return;
+            float* t = scratch + L.scratch_off;
+            float* s = t + L.cols;
+            const float* vin = power_iter ? t : L.v;
+            const float* w = L.w + (long)r * L.cols;
+            float dot = 0.f, nn = 0.f;
+            if ((L.cols & 3) == 0) {
+                // 16-byte loads, four of them in flight per lane (the scalar loop was one dependent round trip per 64 columns)
+                const float4* w4 = reinterpret_cast<const float4*>(w);
+                const float4* v4 = reinterpret_cast<const float4*>(vin);
+                const int n4 = L.cols >> 2;
+#pragma unroll 4
+                for (int c = lane; c < n4; c += 64) {
+                    const float4 a = w4[c], tv = v4[c];
+                    dot += a.x * tv.x + a.y * tv.y + a.z * tv.z + a.w * tv.w;
+                    nn += tv.x * tv.x + tv.y * tv.y + tv.z * tv.z + tv.w * tv.w;
+                }
+            } else {
+#pragma unroll 4
+                for (int c = lane; c < L.cols; c += 64) {
+                    const float tv = vin[c];
+                    dot += w[c] * tv;
+                    nn += tv * tv;
+                }
+            }
+            dot = wave_sum(dot);
+            nn = wave_sum(nn);
+            float inv = 1.f;
+            if (power_iter) inv = 1.f / fmaxf(sqrtf(nn), SN_EPS);
+            if (lane == 0) s[r] = dot * inv;
+            if (power_iter && r == 0) {
+                // v <- t/||t|| : persistent buffer now, snapshot (in place over t) by the pack kernel later would
+                // race with other rows still reading t, so only the persistent copy is written here.
+                for (int c = lane; c < L.cols; c += 64) L.v[c] = vin[c] * inv;
+            }
+        });
 }
 
 // phase 3: one block per layer finalizes u / sigma and takes the (u, v) snapshots the backward of this forward needs.
@@ -141,11 +216,35 @@ __global__ __launch_bounds__(256) void sn_pack_kernel(const sp_sn_layer* __restr
     __shared__ float tile[SN_TILE * (SN_TILE * SN_MAX_TAPS + 1)];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int run = SN_TILE * taps;                     // floats per source row of this tile
-    for (int r = wave; r < SN_TILE; r += 4) {
-        const int co = co0 + r;
-        const float* src = L.w + (long)co * L.cols + (long)ci0 * taps;
-        const int valid = co < L.rows ? min(run, L.cols - ci0 * taps) : 0;
-        for (int k = lane; k < run; k += 64) tile[r * pitch + k] = k < valid ? src[k] * inv_sigma : 0.f;
+    // source tile -> LDS.  The 3x3 and 1x1 cases are unrolled completely (36 / 4 independent loads per thread in flight; the
+    // generic loop below waited for every load before the next: most of the kernel's 68 us)
+    const float* src0 = L.w + (long)co0 * L.cols + (long)ci0 * taps;
+    const int vrun = min(run, L.cols - ci0 * taps);
+    auto stage = [&](auto taps_c) {
+        constexpr int TAPS = decltype(taps_c)::value, RUN = SN_TILE * TAPS, PITCH = RUN + 1, N = SN_TILE * RUN / 256;
+        float v[N];
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+            const int e = threadIdx.x + q * 256;
+            const int r = e / RUN, k = e - r * RUN;
+            v[q] = (co0 + r < L.rows && k < vrun) ? src0[(long)r * L.cols + k] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+            const int e = threadIdx.x + q * 256;
+            const int r = e / RUN, k = e - r * RUN;
+            tile[r * PITCH + k] = v[q] * inv_sigma;
+        }
+    };
+    if (taps == 9) stage(std::integral_constant<int, 9>{});
+    else if (taps == 1) stage(std::integral_constant<int, 1>{});
+    else {
+        for (int r = wave; r < SN_TILE; r += 4) {
+            const int co = co0 + r;
+            const float* src = L.w + (long)co * L.cols + (long)ci0 * taps;
+            const int valid = co < L.rows ? vrun : 0;
+            for (int k = lane; k < run; k += 64) tile[r * pitch + k] = k < valid ? src[k] * inv_sigma : 0.f;
+        }
     }
     __syncthreads();
     // a lane writes TWO consecutive elements (4 bytes for bf16): 16 groups of 16 lanes, each group one 32-element row segment
@@ -326,16 +425,15 @@ extern "C" int sp_sn_forward(const sp_sn_layer* table_dev, int32_t n_layers, int
                              int64_t max_pack_elems, float* scratch, int64_t scratch_floats, void* pack_arena,
                              int32_t power_iter, int32_t dtype, int32_t pack_blocks, sp_stream_t stream) {
     SP_CHECK_ARG(table_dev && scratch && pack_arena && pack_blocks >= 0, "sp_sn_forward: null pointer / negative pack_blocks");
-    SP_CHECK_ARG(n_layers > 0 && max_rows > 0 && max_cols > 0 && max_pack_elems > 0, "sp_sn_forward: bad extents");
+    SP_CHECK_ARG(n_layers > 0 && n_layers <= SN_MAX_LAYERS && max_rows > 0 && max_cols > 0 && max_pack_elems > 0, "sp_sn_forward: bad extents");
     SP_CHECK_ARG(dtype == SP_F32 || dtype == SP_BF16, "sp_sn_forward: bad dtype %d", dtype);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (power_iter) {
-        hipLaunchKernelGGL(sn_wtu_kernel, dim3(sp_div_up(max_cols, 256), n_layers, sp_div_up(max_rows, SN_SLAB)), dim3(256), 0, s,
-                           table_dev, scratch);
+        hipLaunchKernelGGL(sn_wtu_kernel, dim3(SN_GRID), dim3(256), 0, s, table_dev, n_layers, scratch);
         hipLaunchKernelGGL(sn_tsum_kernel, dim3(sp_div_up(max_cols, 256), n_layers), dim3(256), 0, s, table_dev, scratch);
         SP_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(sn_wv_kernel, dim3(sp_div_up(max_rows, 4), n_layers), dim3(256), 0, s, table_dev, scratch, power_iter);
+    hipLaunchKernelGGL(sn_wv_kernel, dim3(SN_GRID), dim3(256), 0, s, table_dev, n_layers, scratch, power_iter);
     SP_LAUNCH_CHECK();
     hipLaunchKernelGGL(sn_finalize_kernel, dim3(n_layers), dim3(256), 0, s, table_dev, scratch, power_iter);
     SP_LAUNCH_CHECK();
