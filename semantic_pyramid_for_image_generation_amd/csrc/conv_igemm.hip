@@ -790,6 +790,7 @@ __global__ void conv_finalize_kernel(sp_conv_params p, int ksplit) {
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         const float* src = ws + pix * p.cout + co;
         if ((p.cout & 3) == 0) {
+#pragma unroll 4
             for (int z = 0; z < ksplit; ++z) {
                 const float4 t = *reinterpret_cast<const float4*>(src + z * slab);
                 v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;

@@ -193,6 +193,7 @@ __global__ void linear_finalize_kernel(const float* __restrict__ acc, int nsplit
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const int b = (int)(e / N), n = (int)(e - (long)b * N);
         float v = bias ? bias[n] : 0.f;
+#pragma unroll 8
         for (int z = 0; z < nsplit; ++z) v += acc[z * total + e];
         const long off = (long)b * ldy + n;
         if (res) v += Elem<T>::ld(res + off);

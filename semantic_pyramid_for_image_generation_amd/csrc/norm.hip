@@ -90,7 +90,12 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     const int c = blockIdx.x * FIN_CL + cl;
     double s = 0.0, q = 0.0;
     if (training && c < C)
-        for (int b = bl; b < nparts; b += FIN_NL) { s += part[((long)b * C + c) * 2]; q += part[((long)b * C + c) * 2 + 1]; }
+    {
+        // 8-byte loads, eight in flight (the plain loop waited for every load: 32 dependent round trips, 7 us per launch)
+        const float2* p2 = reinterpret_cast<const float2*>(part);
+#pragma unroll 8
+        for (int b = bl; b < nparts; b += FIN_NL) { const float2 t = p2[(long)b * C + c]; s += t.x; q += t.y; }
+    }
     red[threadIdx.x * 2] = s;
     red[threadIdx.x * 2 + 1] = q;
     __syncthreads();
@@ -270,10 +275,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
             float sc, bi;
             aff.get(n, c, C, sc, bi);
             double a = 0.0, b = 0.0;
-            for (int k = 0; k < nparts; ++k) {
-                a += part[(((long)n * nparts + k) * C + c) * 2];
-                b += part[(((long)n * nparts + k) * C + c) * 2 + 1];
-            }
+            const float2* p2 = reinterpret_cast<const float2*>(part) + (long)n * nparts * C + c;
+#pragma unroll 8
+            for (int k = 0; k < nparts; ++k) { const float2 t = p2[(long)k * C]; a += t.x; b += t.y; }
             s1 += sc * a;
             s2 += sc * b;
             ga += b;
