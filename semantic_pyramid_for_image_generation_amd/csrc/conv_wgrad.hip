@@ -530,6 +530,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     float dpart = 0.f;
     for (long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4; e < n_dw; e += (long)gridDim.x * 1024) {
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll 8
         for (int sidx = 0; sidx < nsplit; ++sidx) {
             const float4 b = *reinterpret_cast<const float4*>(slabs + (long)sidx * n_dw + e);
             a0 += b.x; a1 += b.y; a2 += b.z; a3 += b.w;
@@ -551,6 +552,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (bias_slabs != nullptr && blockIdx.x == 0) {
         for (int c = threadIdx.x; c < cout; c += 256) {
             double t = 0.0;
+#pragma unroll 8
             for (int sidx = 0; sidx < nsplit; ++sidx) t += bias_slabs[(long)sidx * bias_ld + c];
             dbias[c] += (float)t;
         }

@@ -370,6 +370,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_reduce_kernel(const float
         float t = 0.f;
         // ordered: block 0 of the pair alone sums all partials (fixed order) and is the only writer of its dbias entries
         const int kstep = ordered ? 4 : gridDim.x * 4;
+#pragma unroll 8
         for (int k = (ordered ? 0 : blockIdx.x * 4) + grp; k < nblk; k += kstep) t += bp[(long)k * 64];
         bred[threadIdx.x] = t;
         __syncthreads();
@@ -384,6 +385,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_reduce_kernel(const float
     const int t = e4 / (64 * 16), co = co0 + (e4 / 16) % 64, ci = ci0 + (e4 % 16) * 4;
     if (co >= COUT || ci >= CIN || (int)blockIdx.z >= nblk) return;
     float4 s = reinterpret_cast<const float4*>(base + (long)blockIdx.z * (9 * 64 * 64))[e4];
+    // (unrolled: the loads of eight slabs fly together - the plain loop waited for each: 17 us per launch for 75 MB)
+#pragma unroll 8
     for (int k = blockIdx.z + gridDim.z; k < nblk; k += gridDim.z) {
         const float4 v = reinterpret_cast<const float4*>(base + (long)k * (9 * 64 * 64))[e4];
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;

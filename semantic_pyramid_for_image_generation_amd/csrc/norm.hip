@@ -140,6 +140,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
             a[r] = sc * invstd[c + r];
             b[r] = bi - mean[c + r] * a[r];
         }
+#pragma unroll 4
         for (long p = (long)blockIdx.x * L.pix_par + L.pl; p < hw; p += (long)gridDim.x * L.pix_par) {
             float v[V];
             VecIO<T, V>::ld(xn + p * C + c, v);
@@ -335,6 +336,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             aff.get(n, c + r, C, sc[r], bi[r]);
             mu[r] = mean[c + r]; is[r] = invstd[c + r]; k1[r] = c1[c + r]; k2[r] = c2[c + r];
         }
+#pragma unroll 4
         for (long p = (long)blockIdx.x * L.pix_par + L.pl; p < hw; p += (long)gridDim.x * L.pix_par) {
             float d[V], v[V];
             VecIO<T, V>::ld(dyn + p * C + c, d);
