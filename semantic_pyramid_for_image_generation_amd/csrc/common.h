@@ -147,3 +147,7 @@ long sp_wgrad_rows_workspace(int n, int h, int w, int cin, int cout);
 int sp_wgrad1x1_launch(const void* x, const void* dy, float* dw, float* dbias, int n, int h, int w, int cin, int cout, int ld_dy,
                        float* ws, long ws_floats, hipStream_t s);
 long sp_wgrad1x1_workspace(int n, int h, int w, int cin, int cout, int ld_dy);
+// ... and for the 3x3 layers with an 8-channel input
+int sp_wgrad3x3_cin8_launch(const void* x, const void* dy, float* dw, float* dbias, int n, int h, int w, int cout, int ld_dy, float* ws,
+                            long ws_floats, hipStream_t s);
+long sp_wgrad3x3_cin8_workspace(int n, int h, int w, int cout, int ld_dy);

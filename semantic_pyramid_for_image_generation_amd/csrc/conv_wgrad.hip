@@ -673,6 +673,11 @@ int dispatch_wgrad(const void* x, const void* dy, float* dw, int n, int h, int w
     const T* dt = reinterpret_cast<const T*>(dy);
     const T* wpk = reinterpret_cast<const T*>(w_packed);
     const bool det = sp_deterministic(sizeof(T) == 2 ? SP_BF16 : SP_F32);
+    if (sizeof(T) == 2 && ksize == 3 && cin == 8 && w_packed == nullptr && dot == nullptr) {
+        // the padded RGB images: streaming kernel with an im2col X tile (conv_wgrad_1x1.hip)
+        const int rc = sp_wgrad3x3_cin8_launch(x, dy, dw, dbias, n, h, w, cout, ld_dy, ws, ws_floats, s);
+        if (rc != 1) return rc;
+    }
     if (sizeof(T) == 2 && ksize == 3 && w_packed == nullptr && dot == nullptr) {
         // row-walker kernel (conv_wgrad_rows.hip): all nine taps per block, 4.4x fewer L2 bytes per flop
         if (sp_tune(SP_TUNE_WGRAD_ROWS, 1)) {
@@ -722,6 +727,10 @@ extern "C" int sp_conv2d_wgrad_workspace(int32_t n, int32_t h, int32_t w_, int32
     SP_CHECK_ARG(floats_out && n > 0 && h > 0 && w_ > 0 && cin_p > 0 && cout > 0 && (ksize == 1 || ksize == 3), "sp_conv2d_wgrad_workspace: bad args");
     // scratch the row-walker kernel wants for its per-block partial tiles (bf16, 3x3, W % 32 == 0) ...
     int64_t need = (dtype == SP_BF16 && ksize == 3 && sp_tune(SP_TUNE_WGRAD_ROWS, 1)) ? (int64_t)sp_wgrad_rows_workspace(n, h, w_, cin_p, cout) : 0;
+    if (dtype == SP_BF16 && ksize == 3 && cin_p == 8) {
+        const int64_t s8 = sp_wgrad3x3_cin8_workspace(n, h, w_, cout, (cout + 7) & ~7);
+        if (s8 > need) need = s8;
+    }
     // ... the per-split slabs of the streaming 1x1 kernel ...
     if (dtype == SP_BF16 && ksize == 1) {
         const int64_t s1 = sp_wgrad1x1_workspace(n, h, w_, cin_p, cout, (cout + 7) & ~7);

@@ -169,6 +169,163 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_stream_kernel(W1Args a) {
         }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// 3x3 weight gradient of the layers that read the 8-channel (padded RGB) images: dW[co][tap][8] over 1.3 M pixels, 168 MB of dY
+// and 21 MB of X - a streaming reduction like the 1x1 layers (the row-walking kernel moves 64 pixels per barrier and spends its
+// time in stage overhead: 99 us).  Same ring, same slabs; the X tile is built as an IM2COL row per pixel: the LDS-DMA lane that
+// owns (pixel, tap) fetches the 16 bytes of the tap's neighbour pixel (out-of-image -> zeros), so a row holds 9 x 8 channels +
+// 16 bytes of padding = 160 bytes, and two taps form one 16-column MFMA fragment: dW is a [Cout][72] matrix, its column index
+// the fragment column.  160-byte rows put the 8 rows a transposed read touches on distinct banks without a swizzle.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int C8_BPITCH = 160, C8_BTILE = 64 * C8_BPITCH, C8_STAGE = W1_TILE + C8_BTILE;      // 8 KB dY + 10 KB X rows
+constexpr int C8_LDS = W1_NST * C8_STAGE;                                                     // 72 KB: two blocks per CU
+
+__global__ __launch_bounds__(256, 2) void wgrad3x3_cin8_stream_kernel(W1Args a, int H, int W, int logw, int logh) {
+    extern __shared__ __attribute__((aligned(16))) char w1_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wa = wave >> 1, wb = wave & 1;
+    int split, tile;
+    if (a.nsplit >= 8) {
+        const int xcd = (int)blockIdx.x & 7, q = (int)blockIdx.x >> 3;
+        split = (q / a.tiles) * 8 + xcd;
+        tile = q % a.tiles;
+        if (split >= a.nsplit) return;
+    } else {
+        split = (int)blockIdx.x / a.tiles;
+        tile = (int)blockIdx.x % a.tiles;
+    }
+    const int co0 = tile * 64;
+    const long total_stages = (a.M + 63) / 64;
+    const long st0 = (long)split * a.stages_per_split;
+    const int nk = (int)(total_stages - st0 < a.stages_per_split ? total_stages - st0 : a.stages_per_split);
+    if (nk <= 0) return;
+    const unsigned lds_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)w1_smem);
+
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.x), 0, (int)(a.M * 16), 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.dy), 0, (int)(a.M * a.LD_DY * 2), 0x00020000);
+    const int dpx = lane >> 3;
+    const int dls = ((((lane & 7) >> 1) ^ ((dpx >> 1) & 3)) << 1) | (lane & 1);
+    const bool y_ok = co0 + dls * 8 < a.LD_DY;
+    const unsigned y_lane = (unsigned)((dpx * a.LD_DY + co0 + dls * 8) * 2);
+    // im2col side: chunk q = instruction * 64 + lane of the stage's X tile <-> (pixel q / 10, tap q % 10; tap 9 = padding)
+    const int nxi = wave < 2 ? 3 : 2;                                     // 10 instructions per stage: waves 0, 1 issue three
+    int xq_px[3], xq_dr[3], xq_ds[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int q = (wave + 4 * j) * 64 + lane;
+        const int px = q / 10, tap = q - px * 10;
+        xq_px[j] = px;
+        xq_dr[j] = tap < 9 ? tap / 3 - 1 : 99;                            // 99: padding chunk, never in the image
+        xq_ds[j] = tap < 9 ? tap % 3 - 1 : 0;
+    }
+    auto issue = [&](int ks) {
+        const long pb = (st0 + ks) * 64;
+        char* sb = w1_smem + (ks & (W1_NST - 1)) * C8_STAGE;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int grp = wave + 4 * q;
+            const long row0 = pb + grp * 8;
+            const unsigned yo = (row0 + dpx < a.M && y_ok) ? (unsigned)(row0 * a.LD_DY * 2) + y_lane : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(y_rsrc, (__attribute__((address_space(3))) void*)(sb + grp * 1024), 16, (int)yo, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (j < nxi) {                                                 // wave-uniform
+                const long P = pb + xq_px[j];
+                const int xx = (int)(P & (W - 1)) + xq_ds[j];
+                const int yy = (int)((P >> logw) & (H - 1)) + xq_dr[j];
+                const bool ok = P < a.M && (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H;
+                const unsigned xo = ok ? (unsigned)((P + xq_dr[j] * W + xq_ds[j]) * 16) : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (__attribute__((address_space(3))) void*)(sb + W1_TILE + (wave + 4 * j) * 1024), 16,
+                                                         (int)xo, 0, 0, 0);
+            }
+        }
+    };
+    const int i16 = lane & 15, g = lane >> 4;
+    const int row1 = g * 4 + (i16 >> 2);
+    const int key = (row1 >> 1) & 3;
+    unsigned fa[2], fb[3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) fa[i] = lds_base + (unsigned)(row1 * 128 + (((wa * 2 + i) ^ key) * 32) + (i16 & 3) * 8);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int f = min(wb * 3 + j, 4);                                  // five 16-column fragments; wave half 1 repeats the last
+        fb[j] = lds_base + (unsigned)(W1_TILE + row1 * C8_BPITCH + f * 32 + (i16 & 3) * 8);
+    }
+    const bool do_bias = a.dbias != nullptr && wb == 0;
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
+    f32x4_t acc[2][3], accb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        accb[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    // own requests of one stage: 2 (dY) + 3 or 2 (X)
+    auto wait_landed = [&](int later) {                                    // `later` younger stages may stay in flight
+        if (wave < 2) { if (later == 2) w1_wait_vmcnt<10>(); else if (later == 1) w1_wait_vmcnt<5>(); else w1_wait_vmcnt<0>(); }
+        else { if (later == 2) w1_wait_vmcnt<8>(); else if (later == 1) w1_wait_vmcnt<4>(); else w1_wait_vmcnt<0>(); }
+    };
+
+    issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 2) issue(2);
+    for (int ks = 0; ks < nk; ++ks) {
+        wait_landed(ks + 2 < nk ? 2 : (ks + 1 < nk ? 1 : 0));
+        __builtin_amdgcn_s_barrier();
+        if (ks + 3 < nk) issue(ks + 3);
+        const unsigned sb = (unsigned)((ks & (W1_NST - 1)) * C8_STAGE);
+        uint2 al[2][2], ah[2][2], bl[2][3], bh[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            w1_tr<0>(al[0][i], sb + fa[i]);     w1_tr<2048>(ah[0][i], sb + fa[i]);
+            w1_tr<4096>(al[1][i], sb + fa[i]);  w1_tr<6144>(ah[1][i], sb + fa[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            w1_tr<0>(bl[0][j], sb + fb[j]);                  w1_tr<16 * C8_BPITCH>(bh[0][j], sb + fb[j]);
+            w1_tr<32 * C8_BPITCH>(bl[1][j], sb + fb[j]);     w1_tr<48 * C8_BPITCH>(bh[1][j], sb + fb[j]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bf16x8_t av = w1_frag(al[kk][i], ah[kk][i]);
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w1_frag(bl[kk][j], bh[kk][j]), acc[i][j], 0, 0, 0);
+                if (do_bias) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, ones, accb[i], 0, 0, 0);
+            }
+        }
+    }
+
+    const bool direct = a.slabs == nullptr;
+    float* out = direct ? a.dw : a.slabs + (long)split * a.n_dw;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + (wa * 2 + i) * 16 + g * 4 + r;
+            if (co >= a.COUT) continue;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int f = wb * 3 + j;
+                const int n = f * 16 + i16;                                // = tap * 8 + ci
+                if (f > 4 || n >= 72) continue;
+                const long o = (long)co * 72 + n;
+                if (direct) out[o] += acc[i][j][r]; else out[o] = acc[i][j][r];
+            }
+            if (do_bias && i16 == 0) {
+                if (direct) a.dbias[co] += accb[i][r]; else a.bias_slabs[(long)split * a.bias_ld + co] = accb[i][r];
+            }
+        }
+}
+
 // out[e] += sum_s slab[s][e] for the dW columns and then the bias columns.  A block owns 16 float4 columns; its 16 thread rows
 // take the slabs s = g, g + 16, ... (independent loads) and meet in LDS in a fixed order.
 __global__ __launch_bounds__(256) void wgrad1x1_reduce_kernel(const float* __restrict__ slabs, int nsplit, long n_dw, float* __restrict__ dw,
@@ -276,6 +433,76 @@ int sp_wgrad1x1_launch(const void* x, const void* dy, float* dw, float* dbias, i
         attr_set = true;
     }
     hipLaunchKernelGGL(wgrad1x1_stream_kernel, dim3((unsigned)(p.tiles * (p.nsplit >= 8 ? ((p.nsplit + 7) / 8) * 8 : p.nsplit))), dim3(256), W1_LDS, s, a);
+    SP_LAUNCH_CHECK();
+    if (p.nsplit > 1) {
+        const long cols = a.n_dw / 4 + (a.bias_slabs != nullptr ? a.bias_ld / 4 : 0);
+        hipLaunchKernelGGL(wgrad1x1_reduce_kernel, dim3((unsigned)((cols + 15) / 16)), dim3(256), 0, s, a.slabs, p.nsplit, a.n_dw, dw, a.bias_slabs,
+                           a.bias_ld, cout, dbias);
+        SP_LAUNCH_CHECK();
+    }
+    return SP_OK;
+}
+
+// ---- 3x3, 8-channel input (bf16): same contract
+static bool c8_plan(int n, int h, int w, int cout, int ld_dy, W1Plan& p) {
+    const int target = sp_tune(SP_TUNE_WGRAD1X1, 256);
+    const long M = (long)n * h * w;
+    if (target <= 0 || (h & (h - 1)) != 0 || (w & (w - 1)) != 0 || ld_dy % 8 != 0) return false;
+    if (M * 16 >= (1L << 31) || M * ld_dy * 2 >= (1L << 31) || M < 16384) return false;     // small maps: the row-walker is fine
+    p.ci_tiles = 1;
+    p.tiles = (cout + 63) / 64;
+    const long stages = (M + 63) / 64;
+    long nsplit = (target + p.tiles - 1) / p.tiles;
+    if (nsplit > stages / 4) nsplit = stages / 4;
+    if (nsplit < 1) nsplit = 1;
+    const long sps = (stages + nsplit - 1) / nsplit;
+    p.stages_per_split = (int)sps;
+    p.nsplit = (int)((stages + sps - 1) / sps);
+    p.ok = true;
+    return true;
+}
+
+long sp_wgrad3x3_cin8_workspace(int n, int h, int w, int cout, int ld_dy) {
+    W1Plan p;
+    if (!c8_plan(n, h, w, cout, ld_dy, p) || p.nsplit <= 1) return 0;
+    return (long)p.nsplit * ((long)cout * 72 + ((cout + 3) & ~3));
+}
+
+int sp_wgrad3x3_cin8_launch(const void* x, const void* dy, float* dw, float* dbias, int n, int h, int w, int cout, int ld_dy, float* ws,
+                            long ws_floats, hipStream_t s) {
+    W1Plan p;
+    if (!c8_plan(n, h, w, cout, ld_dy, p)) return 1;
+    W1Args a;
+    a.x = reinterpret_cast<const bf16*>(x);
+    a.dy = reinterpret_cast<const bf16*>(dy);
+    a.dw = dw;
+    a.dbias = dbias;
+    a.M = (long)n * h * w;
+    a.n_dw = (long)cout * 72;
+    a.CIN = 8; a.COUT = cout; a.LD_DY = ld_dy;
+    a.ci_tiles = 1;
+    a.tiles = p.tiles;
+    a.stages_per_split = p.stages_per_split;
+    a.nsplit = p.nsplit;
+    a.bias_ld = (cout + 3) & ~3;
+    a.slabs = nullptr;
+    a.bias_slabs = nullptr;
+    if (p.nsplit > 1) {
+        if (ws == nullptr || ws_floats < (long)p.nsplit * (a.n_dw + a.bias_ld)) return 1;
+        a.slabs = ws;
+        a.bias_slabs = dbias != nullptr ? ws + (long)p.nsplit * a.n_dw : nullptr;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_cin8_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C8_LDS);
+        if (e != hipSuccess) { sp_set_error("hipFuncSetAttribute(LDS=%d) failed: %s", C8_LDS, hipGetErrorString(e)); return SP_ERR_LAUNCH; }
+        attr_set = true;
+    }
+    int logw = 0, logh = 0;
+    while ((1 << logw) < w) ++logw;
+    while ((1 << logh) < h) ++logh;
+    hipLaunchKernelGGL(wgrad3x3_cin8_stream_kernel, dim3((unsigned)(p.tiles * (p.nsplit >= 8 ? ((p.nsplit + 7) / 8) * 8 : p.nsplit))), dim3(256), C8_LDS, s, a,
+                       h, w, logw, logh);
     SP_LAUNCH_CHECK();
     if (p.nsplit > 1) {
         const long cols = a.n_dw / 4 + (a.bias_slabs != nullptr ? a.bias_ld / 4 : 0);

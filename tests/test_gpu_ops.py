@@ -225,14 +225,14 @@ def test_conv1x1_splitk_matches_direct_kernel_with_residuals():
     assert float((y_split - y_direct).abs().max()) <= 2 ** -7 * float(y_direct.abs().max())
 
 
-WGRAD_1X1_CASES = [(72, 128, 1, 3, 41, 24), (64, 136, 1, 2, 32, 48), (8, 64, 1, 20, 128, 128), (64, 3, 1, 20, 128, 128), (128, 256, 1, 20, 32, 32),
+WGRAD_1X1_CASES = [(8, 64, 3, 2, 128, 128), (8, 48, 3, 3, 64, 128), (72, 128, 1, 3, 41, 24), (64, 136, 1, 2, 32, 48), (8, 64, 1, 20, 128, 128), (64, 3, 1, 20, 128, 128), (128, 256, 1, 20, 32, 32),
                    (256, 32, 1, 20, 16, 16)]
 
 
 @pytest.mark.parametrize("case", WGRAD_1X1_CASES)
 def test_conv1x1_streaming_weight_gradient_bf16(case):
-    """wgrad1x1_stream_kernel (conv_wgrad_1x1.hip): long pixel ranges per block, LDS-DMA ring, transposed LDS reads, slabs + ordered
-    reduce.  Ragged pixel counts (a partial last 64-pixel stage, 9 splits on 8 XCDs), partial channel tiles (Cin 72 / 8, Cout 136 / 3)
+    """wgrad1x1_stream_kernel / wgrad3x3_cin8_stream_kernel (conv_wgrad_1x1.hip; the first two cases: 3x3 on the 8-channel input with
+    its im2col X tile): long pixel ranges per block, LDS-DMA ring, transposed LDS reads, slabs + ordered reduce.  Ragged pixel counts (a partial last 64-pixel stage, 9 splits on 8 XCDs), partial channel tiles (Cin 72 / 8, Cout 136 / 3)
     and the step's own shapes; the weight and bias gradients of two runs are bit-identical (no atomics)."""
     test_sn_conv_forward_backward(case, torch.bfloat16)
     cin, cout, k, n, h, w = case
