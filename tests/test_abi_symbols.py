@@ -37,3 +37,18 @@ def test_struct_layouts_match_header():
     assert [n for n, _ in _lib.SpConvParams._fields_] == decl
     sn = re.search(r"typedef struct sp_sn_layer \{(.*?)\}", text, flags=re.S).group(1)
     assert [n for n, _ in _lib.SpSnLayer._fields_] == re.findall(r"(\w+)\s*[;,]", sn)
+
+
+def test_tuning_keys_match_header_and_are_accepted():
+    """Every SP_TUNE_* key of the header has its SP_* environment name in the binding (same index), the library accepts all of
+    them and rejects the first index past SP_TUNE_COUNT (sp_set_tuning touches no device state: callable without a GPU)."""
+    text = re.sub(r"/\*.*?\*/", "", open(_lib.HEADER).read(), flags=re.S)
+    enum = re.search(r"enum \{\s*(SP_TUNE_CONV_TALL.*?)\};", text, flags=re.S).group(1)
+    keys = {k: int(v) for k, v in re.findall(r"(SP_TUNE_\w+)\s*=\s*(\d+)", enum)}
+    count = keys.pop("SP_TUNE_COUNT")
+    assert sorted(keys.values()) == list(range(count))
+    assert {k.replace("SP_TUNE_", "SP_"): v for k, v in keys.items()} == _lib.TUNE_KEYS
+    lib = _lib.lib()
+    for v in keys.values():
+        assert lib.sp_set_tuning(v, -1) == 0
+    assert lib.sp_set_tuning(count, 0) != 0
