@@ -1,0 +1,26 @@
+"""Cycle breakdown of the ping-pong kernel (TIMING instantiation: SP_CONV_PP_PRIO bit 2)."""
+import sys; sys.path.insert(0, '.')
+import ctypes, torch
+from semantic_pyramid_for_image_generation_amd import ops, _lib as L
+lib = L.lib(); dt = torch.bfloat16; B = 20
+names = ["frag reads issue", "vmcnt wait", "barrier after L", "mfma segment", "barrier after M", "epilogue+init", "dma issue", "lgkm wait"]
+for cin, cout, hw in [(128, 128, 128), (256, 256, 64), (64, 128, 128)]:
+    x = ops.nhwc_empty(B, cin, hw, hw, dt, 'cuda'); x.normal_()
+    w = (torch.randn(cout * 9 * cin, device='cuda') * 0.05).to(dt)
+    bias = torch.randn(cout, device='cuda'); y = ops.nhwc_empty(B, cout, hw, hw, dt, 'cuda')
+    ws = torch.zeros(256 * 8 * 8, device='cuda')
+    lib.sp_set_tuning(21, 8); lib.sp_set_tuning(22, int(sys.argv[1]) if len(sys.argv) > 1 else 5)
+    p = L.SpConvParams()
+    p.x, p.w, p.bias, p.y = x.data_ptr(), w.data_ptr(), bias.data_ptr(), y.data_ptr()
+    p.n, p.h, p.w_, p.cin_p, p.cout, p.ldy, p.ksize, p.act, p.dtype = B, hw, hw, cin, cout, cout, 3, 1, 1
+    p.workspace, p.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    for _ in range(3):
+        L.call("sp_conv2d_igemm", ctypes.byref(p), ops.stream())
+    torch.cuda.synchronize()
+    t = ws.view(256, 8, 8)[:, :, :8]
+    for half, sl in (("waves 0-3", slice(0, 4)), ("waves 4-7", slice(4, 8))):
+        m = t[:, sl, :].mean(dim=(0, 1)); tot = m.sum().item()
+        print("%d->%d @%d %s: total %.0f cycles | " % (cin, cout, hw, half, tot) + " | ".join("%s %.1f%%" % (n, 100 * v / tot) for n, v in zip(names, m.tolist())))
+    stages = (B * (hw // 8) * (hw // 32) * ((cout + 127) // 128) / 256) * ((cin + 31) // 32) * 3
+    print("   stages per block %.1f -> cycles per stage %.0f" % (stages, t.sum(dim=2).mean().item() / stages))
+lib.sp_set_tuning(21, -1); lib.sp_set_tuning(22, -1)

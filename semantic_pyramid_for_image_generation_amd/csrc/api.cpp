@@ -15,7 +15,10 @@ extern "C" const char* sp_last_error_string(void) { return g_err; }
 extern "C" int sp_version(void) { return SP_VERSION; }
 
 // knobs for tests and A/B runs (-1 = built-in default); the library itself never reads the environment
-int sp_g_tune[SP_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+struct SpTuneInit { int v[SP_TUNE_COUNT]; SpTuneInit() { for (int i = 0; i < SP_TUNE_COUNT; ++i) v[i] = -1; } };
+static SpTuneInit g_tune_init;
+extern int* const sp_g_tune;
+int* const sp_g_tune = g_tune_init.v;
 extern "C" int sp_set_tuning(int32_t key, int32_t value) {
     if (key < 0 || key >= SP_TUNE_COUNT) { sp_set_error("sp_set_tuning: unknown key %d", key); return SP_ERR_INVALID; }
     sp_g_tune[key] = value;

@@ -87,8 +87,14 @@ template <int N>
 __device__ __forceinline__ void apply_act_vec(float (&v)[N], int act) {
     if (act == SP_ACT_NONE) return;
     if (act == SP_ACT_LRELU) {
+        // max(v, 0.2 v) is LeakyReLU(0.2) bit for bit (v > 0: v > 0.2 v; v < 0: 0.2 v > v; +-0 and NaN likewise), in one multiply
+        // (packed by the compiler) and one v_max instead of multiply + compare + select; plain asm: fmaxf() adds a canonicalising
+        // v_max in front of every operand
 #pragma unroll
-        for (int r = 0; r < N; ++r) v[r] = v[r] > 0.f ? v[r] : 0.2f * v[r];
+        for (int r = 0; r < N; ++r) {
+            const float s = 0.2f * v[r];
+            asm("v_max_f32 %0, %1, %2" : "=v"(v[r]) : "v"(v[r]), "v"(s));
+        }
     } else if (act == SP_ACT_RELU) {
 #pragma unroll
         for (int r = 0; r < N; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -135,10 +141,12 @@ template <> struct VecIO<bf16, 8> {
 };
 
 // knobs (sp_set_tuning, api.cpp); -1 = default
-extern int sp_g_tune[SP_TUNE_COUNT];
+extern int* const sp_g_tune;
 static inline int sp_tune(int key, int dflt) { return sp_g_tune[key] >= 0 ? sp_g_tune[key] : dflt; }
 // fixed-order reductions (no fp32 atomics): always in the fp32 parity mode, on request in the bf16 throughput mode
 static inline bool sp_deterministic(int dtype) { return sp_g_tune[SP_TUNE_DETERMINISTIC] >= 0 ? sp_g_tune[SP_TUNE_DETERMINISTIC] != 0 : dtype == SP_F32; }
+// conv_pp.hip: SP_OK after launching, 1 if the shape is not covered (bf16 3x3, Cout > 64, th x 32 patches with th = 8 / 16)
+int sp_conv_pp_launch(const sp_conv_params& p, int th, hipStream_t s);
 // conv_wgrad_rows.hip: SP_OK after launching, 1 if the shape is not covered
 int sp_wgrad_rows_launch(const void* x, const void* dy, float* dw, float* dbias, int n, int h, int w, int cin, int cout,
                          int ld_dy, float* ws, long ws_floats, int dy_up2, hipStream_t s);

@@ -1,0 +1,160 @@
+// Pieces shared by the implicit-GEMM convolution kernels (conv_igemm.hip, conv_pp.hip): MFMA wrappers, compile-time loops,
+// the epilogues (bias / activation-derivative mask / residuals / activation / 2x2 pooling) and the inline-asm LDS / wait helpers.
+#pragma once
+#include <cstdlib>
+#include <type_traits>
+#include <utility>
+#include "common.h"
+
+namespace {
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16> {
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    }
+};
+
+template <int... I, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+template <typename T>
+__device__ __forceinline__ void conv_epilogue4(const sp_conv_params& p, float (&v)[4], long pix, int co, bool vec_ok, bool add_bias = true) {
+    T* __restrict__ yg = reinterpret_cast<T*>(p.y);
+    const T* r1 = reinterpret_cast<const T*>(p.res1);
+    const T* r2 = reinterpret_cast<const T*>(p.res2);
+    const T* ms = reinterpret_cast<const T*>(p.mask_src);
+    const long off = pix * p.ldy + co;
+    if (vec_ok) {
+        if (p.bias && add_bias) {
+            const float4 bv = *reinterpret_cast<const float4*>(p.bias + co);
+            v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+        }
+        float t[4];
+        if (ms) {
+            Elem<T>::ld4(ms + off, t);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= (t[r] > 0.f ? 1.f : p.mask_neg_slope);
+        }
+        if (r1) { Elem<T>::ld4(r1 + off, t); v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
+        if (r2) { Elem<T>::ld4(r2 + off, t); v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
+        apply_act_vec<4>(v, p.act);
+        Elem<T>::st4(yg + off, v);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (co + r >= p.cout) break;
+            float sv = v[r];
+            if (p.bias && add_bias) sv += p.bias[co + r];
+            if (ms) sv *= (Elem<T>::ld(ms + off + r) > 0.f ? 1.f : p.mask_neg_slope);
+            if (r1) sv += Elem<T>::ld(r1 + off + r);
+            if (r2) sv += Elem<T>::ld(r2 + off + r);
+            Elem<T>::st(yg + off + r, apply_act(sv, p.act));
+        }
+    }
+}
+
+// 16 consecutive output channels of one pixel (the tall kernel's permuted fragment rows): 16-byte loads / stores.
+template <typename T> struct Wide16;
+template <> struct Wide16<bf16> {
+    static __device__ __forceinline__ void ld(const bf16* p, float (&o)[16]) {
+        const uint4 a = *reinterpret_cast<const uint4*>(p), b = *reinterpret_cast<const uint4*>(p + 8);
+        const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { o[2 * k] = bf16_bits_to_f32(w[k] & 0xffffu); o[2 * k + 1] = bf16_bits_to_f32(w[k] >> 16); }
+    }
+    static __device__ __forceinline__ void st(bf16* p, const float (&o)[16]) {
+        uint32_t w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w[k] = f32x2_to_bf16x2(o[2 * k], o[2 * k + 1]);
+        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+        *reinterpret_cast<uint4*>(p + 8) = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+};
+template <> struct Wide16<float> {
+    static __device__ __forceinline__ void ld(const float* p, float (&o)[16]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const float4 t = *reinterpret_cast<const float4*>(p + 4 * k); o[4 * k] = t.x; o[4 * k + 1] = t.y; o[4 * k + 2] = t.z; o[4 * k + 3] = t.w; }
+    }
+    static __device__ __forceinline__ void st(float* p, const float (&o)[16]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(p + 4 * k) = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+    }
+};
+template <typename T>
+__device__ __forceinline__ void conv_epilogue16(const sp_conv_params& p, float (&v)[16], long pix, int co, bool add_bias = true) {
+    T* __restrict__ yg = reinterpret_cast<T*>(p.y);
+    const T* r1 = reinterpret_cast<const T*>(p.res1);
+    const T* r2 = reinterpret_cast<const T*>(p.res2);
+    const T* ms = reinterpret_cast<const T*>(p.mask_src);
+    const long off = pix * p.ldy + co;
+    float t[16];
+    if (p.bias && add_bias) {
+        Wide16<float>::ld(p.bias + co, t);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += t[r];
+    }
+    if (ms) {
+        Wide16<T>::ld(ms + off, t);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] *= (t[r] > 0.f ? 1.f : p.mask_neg_slope);
+    }
+    if (r1) {
+        Wide16<T>::ld(r1 + off, t);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += t[r];
+    }
+    if (r2) {
+        Wide16<T>::ld(r2 + off, t);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += t[r];
+    }
+    apply_act_vec<16>(v, p.act);
+    Wide16<T>::st(yg + off, v);
+}
+
+// 2x2 average pooling fused into the epilogue (pool2): the two rows of a pair are two fragments of the SAME lane, the two
+// columns sit in lanes l and l ^ 1 (DPP quad_perm [1,0,3,2]).  a / b: vertical sums of the column halves 0..15 / 16..31 of a
+// 32-pixel row pair.  Even lanes finish the pooled pixel of half a, odd lanes the one of half b, so every lane stores one
+// pooled pixel x 16 channels; bias / residuals / activation apply at the pooled resolution (conv_epilogue16 on pooled pixels).
+__device__ __forceinline__ float dpp_xor1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+// pool2 == 2: 2x2 MAX pooling (the frozen VGG-16 stages: conv -> ReLU -> MaxPool; bias and a monotonic activation commute
+// with the maximum, and so does the bf16 rounding: bit-identical to the separate pooling kernel).
+__device__ __forceinline__ float pool2_combine(float x, float y, bool is_max) { return is_max ? fmaxf(x, y) : x + y; }
+template <typename T>
+__device__ __forceinline__ void conv_epilogue_pool2(const sp_conv_params& p, const float (&a)[16], const float (&b)[16], int lane,
+                                                    long ppix_row, int pcol0, int co, bool add_bias = true) {
+    const bool odd = lane & 1;
+    const bool is_max = p.pool2 == 2;
+    float v[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const float recv = dpp_xor1(odd ? a[c] : b[c]);
+        const float mine = odd ? b[c] : a[c];
+        v[c] = is_max ? fmaxf(mine, recv) : (mine + recv) * 0.25f;
+    }
+    conv_epilogue16<T>(p, v, ppix_row + pcol0 + (odd ? 8 : 0) + ((lane & 15) >> 1), co, add_bias);
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int OFF> __device__ __forceinline__ void lds_rd128(uint4& d, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "i"(OFF));
+}
+template <int N> __device__ __forceinline__ void wait_lgkm() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+}  // namespace

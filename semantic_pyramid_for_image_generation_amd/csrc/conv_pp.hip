@@ -1,0 +1,419 @@
+// 3x3 convolution (forward / input gradient), Cout > 64: the "ping-pong" kernel.
+//
+// Same tile, LDS image and epilogues as conv3x3_tall_kernel<T, 2, TH> (conv_igemm.hip): a block of 8 waves owns 128 output
+// channels x (TH x 32) pixels, wave (wco, wpx) = 64 channels x (TH/4 rows x 32 columns); K is walked in 64-byte channel chunks,
+// one STAGE = one tap column (3 taps) of a chunk; both operands arrive by LDS-DMA (buffer_load ... lds); the block is
+// persistent and the DMA stream runs across work items.  What is new is the SCHEDULE (MI355X_MICROARCH.md, "Two waves per
+// SIMD"; cdna_hip_programming.md, 8-phase template):
+//
+//   * the tall kernel opens every stage with `s_waitcnt vmcnt(0); s_barrier` for all eight waves, so the two waves of a SIMD
+//     request together, read LDS together and multiply together (matrix || matrix, memory || memory: its matrix pipe is busy
+//     44 % of the time, profiles/README.md).  Here a wave alternates a LOAD segment (all fragment reads of the coming MFMA
+//     segment + its share of the LDS-DMA requests + the counted wait for the data of the NEXT stage) with an MFMA segment
+//     (48 back-to-back MFMAs on registers only), one barrier between segments, and the two halves of the block (waves 0-3 /
+//     4-7 = the two waves of every SIMD) run ONE SEGMENT APART: while one wave of a SIMD multiplies, its partner loads.
+//
+//        interval   0        1        2        3        4
+//        waves 0-3  L(g)     M(g)     L(g+1)   M(g+1)   L(g+2)  ...
+//        waves 4-7  M(g-1)   L(g)     M(g)     L(g+1)   M(g+1)  ...
+//
+//   * vmcnt is never drained in the loop.  Weights live in a 4-slot ring and are requested THREE stages ahead, the halo of
+//     chunk c+1 during the first two stages of chunk c, and the requests are issued INSIDE the MFMA segment, one LDS-DMA
+//     instruction behind each group of 8 MFMAs (its ~60-150 issue cycles hide behind the wave's own queued matrix work; in the
+//     LOAD segment they made it longer than the partner's MFMA segment).  Every wave issues the same number of wave-instructions per stage
+//     (requests past the end of the block's work, and halo pieces past the end of the tile, go to a dummy LDS kilobyte with an
+//     out-of-range offset = zero fill, no memory traffic), so every wait is `vmcnt(pieces issued since)` with a compile-time
+//     count.  Epilogue stores no longer stall the pipeline head: they are older than nothing the next wait needs.
+//   * hazards by construction: a LOAD segment ends with `lgkmcnt(0)` BEFORE its barrier, so when any wave passes barrier k all
+//     LDS reads issued before it have returned; a ring slot is re-requested >= 1 barrier after its last read (WAR), and data is
+//     read >= 1 barrier after the counted wait of EVERY wave that requested a piece of it (RAW; the half that runs ahead reads
+//     two barriers after its own wait).
+//   * the bias vector sits in LDS (copied once per block): the accumulators of an item start at the bias without a global
+//     load whose compiler-inserted wait would drain the DMA queue.
+#include "conv_common.h"
+
+namespace {
+
+constexpr int PP_TW = 32;
+constexpr int PP_NUM_CU = 256;                 // MI355X
+constexpr int PP_BIAS_MAX = 1024;              // output channels whose bias fits the LDS copy
+
+template <typename T, int TH>
+struct PPGeom {
+    static constexpr int E = 16 / (int)sizeof(T), KC = 4 * E;
+    static constexpr int CO_T = 128, WPX = 4, RW = TH / WPX, NB = RW + 2, NFR = RW * 2, HR = TH + 2;
+    static constexpr int HP = TH == 8 ? 40 : 36;                     // halo pitch in pixels (36: swizzle key bit 1 flips on odd rows)
+    static constexpr int HALO_INSTR = (HR * HP * 64 + 1023) / 1024;   // wave-instructions of 1 KB per halo chunk
+    static constexpr int HALO_BUF = HALO_INSTR * 1024;
+    static constexpr int HPW = (HALO_INSTR + 7) / 8;                  // ... per wave (round robin; the tail ones are dummies)
+    static constexpr int HPS0 = (HPW + 1) / 2, HPS1 = HPW - HPS0;     // issued in stage 0 / stage 1 of the previous chunk
+    static constexpr int W_BYTES = 3 * CO_T * 64, W_PER = 3;          // one weight stage = 24 wave-instructions, 3 per wave
+    static constexpr int NWS = 4;                                     // weight ring slots
+    static constexpr int OFF_W = 2 * HALO_BUF, OFF_BIAS = OFF_W + NWS * W_BYTES, OFF_DUMMY = OFF_BIAS + PP_BIAS_MAX * 4;
+    static constexpr int LDS = OFF_DUMMY + 1024;
+};
+
+// number of (halo row h', tap row dr') MFMA groups that precede group (h, dr) in the MFMA segment's order (h outer, dr inner)
+constexpr int pp_group_index(int h, int dr, int rw) {
+    int k = 0;
+    for (int hh = 0; hh <= h; ++hh)
+        for (int d = 0; d < 3; ++d) {
+            if (hh == h && d == dr) return k;
+            if (hh - d >= 0 && hh - d < rw) ++k;
+        }
+    return k;
+}
+
+template <typename T, int TH, int PRIO, bool TIMING = false, bool DMA_IN_L = true>
+__global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int cotiles, int total, int prio) {
+    using G = PPGeom<T, TH>;
+    constexpr int E = G::E, KC = G::KC, CO_T = G::CO_T, WPX = G::WPX, RW = G::RW, NB = G::NB, NFR = G::NFR, HR = G::HR, HP = G::HP;
+    constexpr int HALO_INSTR = G::HALO_INSTR, HALO_BUF = G::HALO_BUF, HPW = G::HPW, W_BYTES = G::W_BYTES, W_PER = G::W_PER;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wave / WPX, wpx = wave % WPX;
+    const bool half_b = wave >= 4;                          // the half of the block that runs one segment behind
+    const int H = p.h, W = p.w_, CIN = p.cin_p;
+    const int tiles_x = W / PP_TW, tiles_y = H / TH;
+    const int kchunks = (CIN + KC - 1) / KC;
+    const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
+    const unsigned lds_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+    // XCD-aware order (as the tall kernel): blocks of one XCD get consecutive work items, co-tiles of a patch adjacent
+    const int GR = gridDim.x;
+    int bid = blockIdx.x;
+    if ((GR & 7) == 0) bid = (bid & 7) * (GR >> 3) + (bid >> 3);
+    const int my_items = (total - bid + GR - 1) / GR;
+    const int nchunks = my_items * kchunks;
+    if (nchunks <= 0) return;
+
+    // ---- bias -> LDS (fp32, zero padded to whole co-tiles), before the first LDS-DMA is in flight
+    {
+        float* bias_l = reinterpret_cast<float*>(smem + G::OFF_BIAS);
+        const int nb = cotiles * CO_T < PP_BIAS_MAX ? cotiles * CO_T : PP_BIAS_MAX;
+        for (int i = tid; i < nb; i += 512) bias_l[i] = (p.bias != nullptr && i < p.cout) ? p.bias[i] : 0.f;
+    }
+
+    // ---- DMA descriptors (raw buffers: SGPR base + 32-bit byte offset per lane; an offset beyond num_records reads zeros)
+    constexpr unsigned OOB = 0x80000000u, OOB_C = 0x40000000u;
+    const int up = p.in_up2 ? 1 : 0;
+    const int HS = H >> up, WS = W >> up;
+    // descriptor inputs through readfirstlane: with the words provably wave-uniform the requests are plain buffer_load ... lds;
+    // otherwise hipcc parks descriptor words in VGPRs under SGPR pressure and wraps every request in a waterfall loop
+    auto uniform_ptr = [](const void* q) {
+        const unsigned long long v = (unsigned long long)(uintptr_t)q;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return (void*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+    };
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.x), 0,
+        __builtin_amdgcn_readfirstlane(p.n * HS * WS * CIN * (int)sizeof(T)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(wg), 0,
+        __builtin_amdgcn_readfirstlane(p.cout * 9 * CIN * (int)sizeof(T)), 0x00020000);
+    const int ls = ((lane & 3) ^ ((lane >> 3) & 3)) * E;   // halo: logical slot (elements) this lane fetches, key (hp >> 1) & 3
+    unsigned h_off[HPW], w_off[W_PER];
+    // work item -> (co-tile, patch column, patch row, image): item k of this block is number bid + k * GR; the mixed-radix digits
+    // advance by the digits of GR with carries (a dozen scalar instructions per item instead of three integer divisions per use)
+    struct Coords { int co_i, tx_i, ty_i, n; };
+    Coords cur, nxt;
+    int s_co, s_tx, s_ty, s_n;
+    {
+        int t = bid;
+        cur.co_i = t % cotiles; t /= cotiles;
+        cur.tx_i = t % tiles_x; t /= tiles_x;
+        cur.ty_i = t % tiles_y; cur.n = t / tiles_y;
+        t = GR;
+        s_co = t % cotiles; t /= cotiles;
+        s_tx = t % tiles_x; t /= tiles_x;
+        s_ty = t % tiles_y; s_n = t / tiles_y;
+    }
+    auto advance = [&](const Coords& c) {
+        Coords r;
+        r.co_i = c.co_i + s_co; int cy = r.co_i >= cotiles ? 1 : 0; r.co_i -= cy ? cotiles : 0;
+        r.tx_i = c.tx_i + s_tx + cy; cy = r.tx_i >= tiles_x ? 1 : 0; r.tx_i -= cy ? tiles_x : 0;
+        r.ty_i = c.ty_i + s_ty + cy; cy = r.ty_i >= tiles_y ? 1 : 0; r.ty_i -= cy ? tiles_y : 0;
+        r.n = c.n + s_n + cy;
+        return r;
+    };
+    nxt = advance(cur);
+    auto set_halo_desc = [&](const Coords& c) {
+        const int n = c.n, ty0 = c.ty_i * TH, tx0 = c.tx_i * PP_TW;
+        int l4 = lane >> 2;
+        asm volatile("" : "+v"(l4));                       // recomputed per item: hoisted out of the loop, the (row, column) pairs of
+                                                           // every piece stay live across it (and spill)
+#pragma unroll
+        for (int i = 0; i < HPW; ++i) {
+            const int hp = (i * 8 + wave) * 16 + l4;                   // piece q = i * 8 + wave
+            const int hy = hp / HP, hx = hp - hy * HP;
+            const int yy = ty0 - 1 + hy, xx = tx0 - 1 + hx;
+            const bool ok = hx < PP_TW + 2 && hy < HR && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            h_off[i] = ok ? (unsigned)((((n * HS + (yy >> up)) * WS + (xx >> up)) * CIN + ls) * (int)sizeof(T)) : OOB;
+        }
+    };
+    // weight rows (stage row = tap row * 128 + co) are swizzled by key = ((co >> 1) & 1) | (((co >> 4) & 1) << 1)
+    auto w_ls = [&](int i) { return ((lane & 3) ^ (((lane >> 3) & 1) | (((wave * W_PER + i) & 1) << 1))) * E; };
+    auto set_w_desc = [&](const Coords& c) {
+        const int co0 = c.co_i * CO_T;
+        int l4 = lane >> 2;
+        asm volatile("" : "+v"(l4));
+#pragma unroll
+        for (int i = 0; i < W_PER; ++i) {
+            const int row = (wave * W_PER + i) * 16 + l4;
+            const int ts = row / CO_T, co = co0 + row % CO_T;          // tap row inside the stage; the stage adds the tap column
+            w_off[i] = co < p.cout ? (unsigned)(((co * 9 + ts * 3) * CIN + w_ls(i)) * (int)sizeof(T)) : OOB;
+        }
+    };
+    auto dma = [&](__amdgpu_buffer_rsrc_t rsrc, unsigned dst /* wave-uniform LDS byte offset */, unsigned voff) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(smem + dst), 16, (int)voff, 0, 0, 0);
+    };
+    // one halo piece (index i of this wave's share of a chunk) / one weight piece; !valid: a dummy request (same count)
+    // (selects written as masks: with `?:` on the wave-uniform condition hipcc branches around every request, which cuts the
+    // MFMA segment into basic blocks)
+    auto issue_halo_piece = [&](int i, bool valid, int c0, int slot) {
+        const unsigned add = c0 + ls < CIN ? (unsigned)(c0 * (int)sizeof(T)) : OOB_C;
+        const int q = i * 8 + wave;
+        const unsigned m = (valid && q < HALO_INSTR) ? 0xffffffffu : 0u;    // wave-uniform
+        dma(x_rsrc, ((unsigned)(slot * HALO_BUF + q * 1024) & m) | ((unsigned)G::OFF_DUMMY & ~m), ((h_off[i] + add) & m) | (OOB & ~m));
+    };
+    auto issue_w_piece = [&](int i, bool valid, int c0, int ds, int slot) {
+        const unsigned base = (unsigned)((ds * CIN + c0) * (int)sizeof(T));
+        const unsigned add = c0 + w_ls(i) < CIN ? base : OOB_C;
+        const unsigned m = valid ? 0xffffffffu : 0u;
+        dma(w_rsrc, ((unsigned)(G::OFF_W + slot * W_BYTES + (wave * W_PER + i) * 1024) & m) | ((unsigned)G::OFF_DUMMY & ~m),
+            ((w_off[i] + add) & m) | (OOB & ~m));
+    };
+
+    // ---- fragment read addresses (the tall kernel's: permuted A rows -> a lane ends with 16 consecutive channels of its pixel)
+    const int frow = lane & 15, fslot = lane >> 4;
+    const unsigned a_addr = lds_base + G::OFF_W + (wco * 64 + (frow >> 2) * 16 + (frow & 3)) * 64 +
+                            ((fslot ^ (((frow >> 1) & 1) | (((frow >> 2) & 1) << 1))) << 4);
+    unsigned b_addr[3];
+#pragma unroll
+    for (int ds = 0; ds < 3; ++ds)
+        b_addr[ds] = lds_base + ((RW * wpx) * HP + frow + ds) * 64 + ((fslot ^ (((frow + ds) >> 1) & 3)) << 4);
+    const unsigned bias_addr = lds_base + G::OFF_BIAS + (wco * 64 + (lane >> 4) * 16) * 4;
+
+    const bool bias_in_acc = p.bias != nullptr && !up && cotiles * CO_T <= PP_BIAS_MAX;
+    f32x4_t acc[4][NFR];
+    auto init_acc = [&](bool live, int co0) {
+        uint4 b4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b4[i] = make_uint4(0, 0, 0, 0);
+        if (bias_in_acc && live) {
+            const unsigned ba = bias_addr + (unsigned)co0 * 4u;
+            lds_rd128<0>(b4[0], ba); lds_rd128<16>(b4[1], ba); lds_rd128<32>(b4[2], ba); lds_rd128<48>(b4[3], ba);
+            wait_lgkm<0>();
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NFR; ++j)
+                acc[i][j] = f32x4_t{__uint_as_float(b4[i].x), __uint_as_float(b4[i].y), __uint_as_float(b4[i].z), __uint_as_float(b4[i].w)};
+    };
+
+    // ---- prologue: chunk 0's halo, weight stages 0, 1 and 2
+    set_halo_desc(cur);
+    set_w_desc(cur);
+#pragma unroll
+    for (int i = 0; i < HPW; ++i) issue_halo_piece(i, true, 0, 0);
+#pragma unroll
+    for (int ds = 0; ds < 3; ++ds)
+#pragma unroll
+        for (int i = 0; i < W_PER; ++i) issue_w_piece(i, true, 0, ds, ds);
+    wait_vmcnt<2 * W_PER>();                                // halo 0 and stage 0 landed (this wave's pieces); stages 1, 2 may fly
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the bias copy
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    init_acc(true, cur.co_i * CO_T);
+    if (half_b) __builtin_amdgcn_s_barrier();               // from here on this half runs one segment behind
+
+    if ((prio & 2) && half_b) __builtin_amdgcn_s_setprio(1);
+    // TIMING build (diagnostics, SP_TUNE_CONV_PP_PRIO bit 2): cycles per wave in [0] LOAD segment up to the counted wait (fragment
+    // reads + DMA issue + LDS latency), [1] the vmcnt wait, [2] barrier after LOAD, [3] MFMA segment, [4] barrier after MFMA,
+    // [5] epilogue + item switch; written to p.workspace[(block * 8 + wave) * 8 + k] (fp32 scratch pointer, unused by this kernel)
+    unsigned long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = 0;
+    auto stamp = [&](int k) {
+        if constexpr (TIMING) {
+            const unsigned long long t = __builtin_readcyclecounter();
+            tacc[k] += t - tprev;
+            tprev = t;
+        }
+    };
+    if constexpr (TIMING) tprev = __builtin_readcyclecounter();
+    int g4 = 0;                                             // weight ring slot of the stage being computed (stage index mod 4)
+    int kc = 0;
+    const bool vec_ok = ((p.ldy & 3) == 0) && ((p.cout & 3) == 0);
+    for (int gc = 0; gc < nchunks; ++gc) {
+        const bool more_chunks = gc + 1 < nchunks;
+        const bool item_ends = kc + 1 == kchunks;
+        const unsigned hb = (unsigned)((gc & 1) * HALO_BUF);
+        const int c0_next = item_ends ? 0 : (kc + 1) * KC;
+        static_for<3>([&](auto sc) {
+            constexpr int st = decltype(sc)::value;        // stage inside the chunk = tap column
+            constexpr int TAP_STRIDE = CO_T * 64;
+            constexpr int NH = st == 0 ? G::HPS0 : st == 1 ? G::HPS1 : 0, H0 = st == 0 ? 0 : G::HPS0;   // halo pieces requested in this stage
+            constexpr int NPIECE = NH + W_PER;
+            const unsigned ab = a_addr + (unsigned)(g4 * W_BYTES);
+            const unsigned bb = b_addr[st] + hb;
+            const unsigned bo = HP == 36 ? (bb ^ 32u) : bb; // odd halo rows (pitch 36): swizzle key flipped in bit 1
+            uint4 a[3][4], bf[NB][2];
+            // ================= LOAD segment: every fragment of the stage =================
+            const int ws = (g4 + 3) & 3;                    // slot of stage g + 3 = slot of stage g - 1 (its reads ended >= two barriers ago)
+            auto piece = [&](auto kc_) {                    // request number k of this stage: halo of the next chunk, then weights of stage g + 3
+                constexpr int k = decltype(kc_)::value;
+                if constexpr (k < NH) issue_halo_piece(H0 + k, more_chunks, c0_next, (gc + 1) & 1);
+                else if constexpr (k < NPIECE) issue_w_piece(k - NH, more_chunks, c0_next, st, ws);
+            };
+            if constexpr (DMA_IN_L && st == 0) {
+                if (item_ends && more_chunks) { set_halo_desc(nxt); set_w_desc(nxt); }
+            }
+            // DMA_IN_L: one request behind every four fragment reads - the reads queue on the LDS pipe, the requests on the texture
+            // path, so neither waits for the other's queue to drain
+            static_for<((12 + 2 * NB + 3) / 4 > NPIECE ? (12 + 2 * NB + 3) / 4 : NPIECE)>([&](auto qc) {
+                constexpr int q0 = decltype(qc)::value * 4;
+                static_for<4>([&](auto rc) {
+                    constexpr int r = q0 + decltype(rc)::value;     // read number: 0..11 = A (tap row r / 4, fragment r % 4), then B rows
+                    if constexpr (r < 12) {
+                        lds_rd128<(r / 4) * TAP_STRIDE + (r % 4) * 256>(a[r / 4][r % 4], ab);
+                    } else if constexpr (r < 12 + 2 * NB) {
+                        constexpr int h = (r - 12) / 2, hh = (r - 12) % 2;
+                        lds_rd128<h * (HP * 64) + hh * 1024>(bf[h][hh], (h & 1) ? bo : bb);
+                    }
+                });
+                if constexpr (DMA_IN_L) piece(qc);
+            });
+            stamp(0);
+            // the NEXT stage's weights were requested two MFMA segments ago, everything younger in the last one: H + W pieces of the
+            // previous stage; before a chunk's first stage the wait also covers the last halo pieces (3 younger weight pieces)
+            if constexpr (DMA_IN_L)     // requests of this and of the previous LOAD segment are younger than the next stage's weights
+                wait_vmcnt<st == 0 ? 2 * W_PER + G::HPS0 : st == 1 ? 2 * W_PER + G::HPS0 + G::HPS1 : 2 * W_PER>();
+            else
+                wait_vmcnt<st == 0 ? W_PER : st == 1 ? G::HPS0 + W_PER : W_PER>();
+            stamp(1);
+            wait_lgkm<0>();                                 // every LDS read of this wave has returned before it signals
+            stamp(7);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(2);
+            // ================= MFMA segment, with this stage's requests behind its MFMA groups =================
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+            if constexpr (!DMA_IN_L && st == 0) {
+                if (item_ends && more_chunks) { set_halo_desc(nxt); set_w_desc(nxt); }
+            }
+            static_for<NB * 3>([&](auto gi) {
+                constexpr int h = decltype(gi)::value / 3, dr = decltype(gi)::value % 3, rr = h - dr;
+                if constexpr (rr >= 0 && rr < RW) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh) Mma<T>::run(a[dr][i], bf[h][hh], acc[i][rr * 2 + hh]);
+                    if constexpr (!DMA_IN_L) piece(std::integral_constant<int, pp_group_index(h, dr, RW)>{});   // behind MFMA group k: request k
+                }
+            });
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(3);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(4);
+            g4 = (g4 + 1) & 3;
+        });
+        if (item_ends) {
+            const int n = cur.n, ty0 = cur.ty_i * TH, tx0 = cur.tx_i * PP_TW, co0 = cur.co_i * CO_T;
+            const long pix0 = ((long)n * H + ty0 + RW * wpx) * W + tx0 + (lane & 15);
+            const int co_b = co0 + wco * 64 + (lane >> 4) * 16;          // this lane's 16 consecutive channels
+            const bool wide = vec_ok && (p.ldy & 7) == 0 && co_b + 16 <= p.cout;
+            if (up) {                                                    // the 1/4 of the average-pooling gradient
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NFR; ++j) acc[i][j] *= 0.25f;
+            }
+            static_for<NFR>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const long pix = pix0 + (long)(j >> 1) * W + (j & 1) * 16;
+                if (p.pool2) {                                           // launcher guarantees `wide`
+                    if constexpr ((j & 3) == 0) {                        // fragments j..j+3 = rows (j>>1, j>>1 + 1) x column halves
+                        float av[16], bv[16];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                av[i * 4 + r] = pool2_combine(acc[i][j][r], acc[i][j + 2][r], p.pool2 == 2);
+                                bv[i * 4 + r] = pool2_combine(acc[i][j + 1][r], acc[i][j + 3][r], p.pool2 == 2);
+                            }
+                        const long prow = ((long)n * (H >> 1) + ((ty0 + RW * wpx + (j >> 1)) >> 1)) * (W >> 1);
+                        conv_epilogue_pool2<T>(p, av, bv, lane, prow, tx0 >> 1, co_b, !bias_in_acc);
+                    }
+                } else if (wide) {
+                    float v[16];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r];
+                    conv_epilogue16<T>(p, v, pix, co_b, !bias_in_acc);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int co = co_b + i * 4;
+                        if (co < p.cout) {
+                            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                            conv_epilogue4<T>(p, v, pix, co, vec_ok, !bias_in_acc);
+                        }
+                    }
+                }
+            });
+            kc = 0;
+            cur = nxt;
+            nxt = advance(nxt);
+            stamp(5);
+            init_acc(more_chunks, cur.co_i * CO_T);
+            stamp(8);
+        } else {
+            ++kc;
+        }
+    }
+    if (!half_b) __builtin_amdgcn_s_barrier();              // the barrier the other half passes after its last MFMA segment
+    if constexpr (TIMING) {
+        if (lane == 0 && p.workspace != nullptr) {
+            float* out = reinterpret_cast<float*>(p.workspace) + ((long)blockIdx.x * 8 + wave) * 8;
+            for (int k = 0; k < 8; ++k) out[k] = (float)tacc[k];
+            out[5] += (float)tacc[8];
+        }
+    }
+}
+
+template <typename T, int TH, int PRIO, bool TIMING = false, bool DMA_IN_L = true>
+int launch_pp(const sp_conv_params& p, int prio, hipStream_t s) {
+    using G = PPGeom<T, TH>;
+    static_assert(G::LDS <= 163840, "LDS budget");
+    static bool attr_set = false;
+    auto kern = conv3x3_pp_kernel<T, TH, PRIO, TIMING, DMA_IN_L>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+        if (e != hipSuccess) { sp_set_error("hipFuncSetAttribute(LDS=%d) failed: %s", G::LDS, hipGetErrorString(e)); return SP_ERR_LAUNCH; }
+        attr_set = true;
+    }
+    const int cotiles = (p.cout + 127) / 128;
+    const int total = p.n * (p.h / TH) * (p.w_ / PP_TW) * cotiles;
+    int grid = total < PP_NUM_CU ? total : PP_NUM_CU;       // persistent: one block per CU
+    if (grid >= 8) grid -= grid % 8;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), G::LDS, s, p, cotiles, total, prio);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+}  // namespace
+
+// conv_igemm.hip's dispatch(): bf16 3x3 layers with more than 64 output channels on (th x 32)-pixel patches, th = 8 or 16.
+// Returns 1 if the shape is not covered (the caller then keeps its own kernel).
+int sp_conv_pp_launch(const sp_conv_params& p, int th, hipStream_t s) {
+    if (p.dtype != SP_BF16 || p.ksize != 3 || p.cout <= 64 || p.h % th != 0 || p.w_ % PP_TW != 0) return 1;
+    const long esz = 2;
+    if ((long)p.n * p.h * p.w_ * p.cin_p * esz >= (1L << 30) || (long)p.cout * 9 * p.cin_p * esz >= (1L << 30)) return 1;
+    const int prio = sp_tune(SP_TUNE_CONV_PP_PRIO, 1);
+    if (th == 8 && (prio & 4)) return (prio & 8) ? launch_pp<bf16, 8, 1, true, false>(p, prio, s) : launch_pp<bf16, 8, 1, true, true>(p, prio, s);
+    if (th == 8 && (prio & 8)) return launch_pp<bf16, 8, 1, false, false>(p, prio, s);
+    if (th == 8) return (prio & 1) ? launch_pp<bf16, 8, 1>(p, prio, s) : launch_pp<bf16, 8, 0>(p, prio, s);
+    return 1;
+}
