@@ -693,16 +693,18 @@ int dispatch_wgrad(const void* x, const void* dy, float* dw, int n, int h, int w
     // throughput mode: the per-tap kernels keep their atomics (their slab mode measured slower); deterministic mode: slabs
     if (!det) { ws = nullptr; ws_floats = 0; }
     int co_t, ci_t;
-    const WgPlan pl = pertap_plan<T>(n, h, w, cin, cout, ksize, co_t, ci_t);
+    WgPlan pl = pertap_plan<T>(n, h, w, cin, cout, ksize, co_t, ci_t);
     const long n_dw = (long)cout * ksize * ksize * cin;
     const int bias_ld = (cout + 3) & ~3;
     // slab mode: every split stores its partial tile (and bias row) with plain stores and a second pass sums them in split
     // order; without it the splits meet through fp32 atomics.  A single split owns its dW rows: no merge either way.
     float* slabs = (ws != nullptr && pl.nsplit > 1 && ws_floats >= (long)pl.nsplit * (n_dw + bias_ld) && (n_dw & 3) == 0) ? ws : nullptr;
     if (det && pl.nsplit > 1 && slabs == nullptr) {
-        sp_set_error("weight gradient: the deterministic mode needs the %ld floats of scratch sp_conv2d_wgrad_workspace() reports (got %ld)",
-                     (long)pl.nsplit * (n_dw + bias_ld), ws_floats);
-        return SP_ERR_INVALID;
+        // deterministic mode without (enough) scratch - sp_conv2d_wgrad has no workspace argument, the others document it as
+        // optional: ONE split per tile, which then owns its dW rows (ordered, no merge; slower than the split plan)
+        const long M = (long)n * h * w;
+        pl.nsplit = 1;
+        pl.per_split = pl.nine ? (long)n * h * (w / Wg9Traits<T>::PXS) : ((M + WgTraits<T>::PK - 1) / WgTraits<T>::PK) * WgTraits<T>::PK;
     }
     float* bias_slabs = (slabs != nullptr && dbias != nullptr) ? slabs + (long)pl.nsplit * n_dw : nullptr;
     int rc;

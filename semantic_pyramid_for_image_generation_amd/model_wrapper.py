@@ -22,6 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import misc, ops
+from .config import CFG
 from .lossfunction import DiversityLoss, LSGANDiscriminatorLoss, LSGANGeneratorLoss, SemanticReconstructionLoss
 from .models import VGG16, Discriminator, Generator
 
@@ -80,7 +81,7 @@ class ModelWrapper(object):
         # D runs twice per backward (real, fake) and its gradients meet there instead of in 59 autograd sums, and the
         # data-parallel reducer all-reduces ranges of the buffer in place.  SP_DIRECT_GRADS=0: plain autograd gradients.
         self._banks = {}
-        if os.environ.get("SP_DIRECT_GRADS", "1") == "1":
+        if CFG.direct_grads:
             for key, net, passes in (("d", self.discriminator, 2), ("g", self.generator, 1)):
                 bank = getattr(net, "_bank", None)
                 if bank is not None:
@@ -89,6 +90,8 @@ class ModelWrapper(object):
                     bank.set_groups(4 if gradient_reducer is not None else 1)
                     self._banks[key] = bank
         self._graph_state = None
+        self.graph_after_iterations = CFG.graph_after       # train(): eager iterations before the step is captured (0 = never)
+        self._eager_run, self._eager_sig, self._graph_failed = 0, None, False
         self._capturing = False
         self._fired = set()
         self.iterations = 0
@@ -136,6 +139,12 @@ class ModelWrapper(object):
             if not any(fa <= a and b <= fb for fa, fb in fired):
                 todo.append((a, b))
         red.reduce_flat(bank.flat, todo)
+        # safety net: a gradient that does not live in the flat buffer (a parameter the bank does not know) is reduced on its own
+        lo = bank.flat.data_ptr()
+        hi = lo + 4 * bank.flat.numel()
+        loose = [p for p in params if p.grad is not None and not (lo <= p.grad.data_ptr() < hi)]
+        if loose:
+            red.reduce(loose)
 
     def _join_reduce(self) -> None:
         if self.gradient_reducer is not None:
@@ -298,6 +307,37 @@ class ModelWrapper(object):
         return st["out"]
 
     # ------------------------------------------------------------------------------------------
+    def _batch_signature(self, images_real, labels, masks):
+        return (tuple(images_real.shape), images_real.dtype, tuple(labels.shape), labels.dtype,
+                tuple((tuple(m.shape), m.dtype) for m in masks), str(images_real.device))
+
+    def _train_iteration(self, images_real, labels, masks, w_rec: float, w_div: float) -> Dict[str, torch.Tensor]:
+        """One iteration of train(): the first ``graph_after_iterations`` batches (config.CFG.graph_after, default 3; 0 = never)
+        run eagerly, then - the batch shapes being static, as with the reference's drop_last loader (main.py:80-88) - the step
+        is captured once and every further batch of the same shapes REPLAYS the three HIP graphs (its tensors are copied into
+        the graphs' static inputs).  A batch of other shapes, or any failure to capture, runs eagerly.  Replay and eager
+        launches execute the same kernels in the same order on the same RNG stream: the logged metrics are identical
+        (tests/test_gpu_frontdoor.py)."""
+        after = self.graph_after_iterations
+        sig = self._batch_signature(images_real, labels, masks)
+        st = self._graph_state
+        if st is not None and st.get("sig") == sig and st.get("w") == (w_rec, w_div):
+            return self.train_step_graphed(images_real, labels, masks)
+        out = self.train_step(images_real, labels, masks, w_rec=w_rec, w_div=w_div)
+        if after and after > 0 and images_real.is_cuda and not self._graph_failed:
+            self._eager_run = self._eager_run + 1 if sig == self._eager_sig else 1
+            self._eager_sig = sig
+            if self._eager_run >= after:
+                try:
+                    self.capture_graphs(images_real, labels, masks, w_rec=w_rec, w_div=w_div)
+                    self._graph_state["sig"] = sig
+                except Exception as exc:                  # a caller's module the capture cannot hold: stay eager, say so once
+                    self._graph_state = None
+                    self._graph_failed = True
+                    import warnings
+                    warnings.warn("ModelWrapper.train(): HIP-graph capture failed (%s); continuing with eager launches" % (exc,))
+        return out
+
     def train(self, epochs: int = 20, validate_after_n_iterations: int = 100000, device: str = 'cuda',
               save_model_after_n_epochs: int = 1, w_rec: float = 0.1, w_div: float = 0.1) -> None:
         """model_wrapper.py:93-228."""
@@ -327,7 +367,7 @@ class ModelWrapper(object):
                 images_real = images_real.detach().to(device)
                 labels = labels.to(device)
                 masks = [m.detach().to(device) for m in masks]
-                out = self.train_step(images_real, labels, masks, w_rec=w_rec, w_div=w_div)
+                out = self._train_iteration(images_real, labels, masks, w_rec, w_div)
                 vals = torch.stack([out[n].float().reshape(()) for n in names]).tolist()      # the single host sync
                 l_div, l_rec, l_g, l_df, l_dr = vals
                 self.progress_bar.set_description(

@@ -21,6 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+from .config import CFG
 from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH
 
 
@@ -91,24 +92,24 @@ class SNEmbedding(nn.Module, _SpectralNormMixin):
         self._register_sn(ref.weight.data, None)
 
 
-_FUSE_LRELU_BWD = os.environ.get("SP_FUSE_LRELU_BWD", "1") == "1"   # A/B switch (profiles/README.md)
+_FUSE_LRELU_BWD = CFG.fuse_lrelu_bwd   # A/B switch (profiles/README.md)
 # The 1x1 residual convolutions commute with the linear resampling next to them (bilinear x2 with align_corners and 2x2
 # average pooling are convex combinations of pixels, so the bias passes through unchanged): conv1x1(upsample(x)) =
 # upsample(conv1x1(x)) and avgpool(conv1x1(x) + m) = conv1x1(avgpool(x)) + avgpool(m).  Running the convolution on the
 # low-resolution side does a quarter of its forward / input-gradient / weight-gradient work; results agree with the
 # reference order to fp32 rounding (tests/test_gpu_step.py).  SP_COMMUTE_1X1=0 restores the reference order.
-_COMMUTE_1X1 = os.environ.get("SP_COMMUTE_1X1", "1") == "1"
+_COMMUTE_1X1 = CFG.commute_1x1
 # The 2x2 average pooling behind the second convolution of a discriminator block (models.py:407-417, 452-462) is computed in
 # that convolution's epilogue from the fp32 accumulators (one rounding instead of two; the full-resolution tensor never
 # reaches HBM).  SP_FUSE_POOL2=0 runs the separate pooling kernel.
-_FUSE_POOL2 = os.environ.get("SP_FUSE_POOL2", "1") == "1"
+_FUSE_POOL2 = CFG.fuse_pool2
 # The input of a discriminator block is read by LeakyReLU -> conv and by AvgPool -> 1x1 conv: one kernel produces both
 # (ops.act_avgpool2), and one backward kernel replaces activation backward + pooling backward + the autograd sum.
-_FUSE_ACT_POOL = os.environ.get("SP_FUSE_ACT_POOL", "1") == "1"
+_FUSE_ACT_POOL = CFG.fuse_act_pool
 # CBN -> LeakyReLU -> UpsamplingBilinear2d of a generator block in one pass (ops.batch_norm(..., upsample=True)): measured
 # SLOWER than the two kernels (897 vs 932 img/s: every source pixel is normalised by four output pixels and the class-gathered
 # affine is re-read per output vector), so it is off by default; the operator stays for A/B runs.
-_FUSE_BN_UPSAMPLE = os.environ.get("SP_FUSE_BN_UPSAMPLE", "0") == "1"
+_FUSE_BN_UPSAMPLE = CFG.fuse_bn_upsample
 
 
 def init_weights(module: nn.Module) -> None:

@@ -14,6 +14,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib as L
+from .config import CFG
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = L.ACT_NONE, L.ACT_LRELU, L.ACT_RELU, L.ACT_TANH
 
@@ -290,16 +291,24 @@ class SpectralNormBank:
         of `flat` (one multi-tensor copy) and .grad becomes the view, so that EVERY gradient of the network lives in `flat`."""
         if not self.direct_grads or self.flat is None:
             return
-        src, dst = [], []
-        for p, v in zip(self.extra_params, self.extra_views):
+        # ... and so do biases of spectral-normalised layers whose gradient came through autograd instead of a kernel's bias slot
+        # (the discriminator's classification head, _DHeadFn.backward: without this its gradient sat outside `flat`, i.e. outside
+        # everything the data-parallel reducer all-reduces)
+        pairs = list(zip(self.extra_params, self.extra_views))
+        for (m, _, _), v in zip(self.specs, self.b_views):
+            b = getattr(m, "bias", None)
+            if b is not None:
+                pairs.append((b, v))
+        src, dst, moved = [], [], []
+        for p, v in pairs:
             if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
-                src.append(p.grad.reshape(v.shape) if p.grad.is_contiguous() else p.grad.contiguous())
+                src.append(p.grad.reshape(v.shape) if p.grad.is_contiguous() else p.grad.contiguous().reshape(v.shape))
                 dst.append(v)
+                moved.append((p, v))
         if src:
             torch._foreach_copy_(dst, src)
-            for p, v in zip(self.extra_params, self.extra_views):
-                if p.grad is not None:
-                    p.grad = v
+            for p, v in moved:
+                p.grad = v
 
     def _build(self, dtype, device):
         e = chunk_elems(dtype)
@@ -484,7 +493,7 @@ def _is_halo128(n, h, w, cout, ksize) -> bool:
 
 TUNE_CONV_TALL, TUNE_IGEMM_DMA, TUNE_WGRAD_ROWS, TUNE_DETERMINISTIC = 0, 1, 2, 3
 TUNE_CONV1X1_SPLITK, TUNE_WGRAD1X1, TUNE_CONV_CIN8, TUNE_CONV_THINCO = 17, 18, 19, 20
-_POOL2_BWD_FUSED = os.environ.get("SP_POOL2_BWD_FUSED", "1") == "1"     # A/B switch (profiles/README.md)
+_POOL2_BWD_FUSED = CFG.pool2_bwd_fused     # A/B switch (profiles/README.md)
 
 
 def set_tuning(key: int, value: int) -> None:

@@ -138,6 +138,35 @@ def test_vgg16_constructor_loads_a_pretrained_file(tmp_path):
         assert torch.equal(x, y)
 
 
+def test_every_gradient_lives_in_the_flat_buffer():
+    """Row e (round-2 ADVICE, high): the data-parallel reducer all-reduces ranges of the networks' flat gradient buffers, so a
+    gradient that autograd leaves OUTSIDE the buffer would silently stay un-averaged on N > 1 ranks.  The discriminator head's
+    classification bias was one (its gradient is returned through autograd, not written by a kernel): after the backward of the
+    D phase / the G phase every parameter's .grad must be a view of its bank's buffer."""
+    ops.set_compute_dtype(torch.float32)
+    G, D, V = build(4, 1)
+    og, od = sp.optim.Adam(G.parameters(), lr=1e-4), sp.optim.Adam(D.parameters(), lr=1e-4)
+    mw = sp.ModelWrapper(generator=G, discriminator=D, vgg16=V, training_dataset=None, validation_dataset=None,
+                         generator_optimizer=og, discriminator_optimizer=od, save_data_path=None)
+    G.train(); D.train()
+    images, labels, masks = gu.golden_batches(4, 1)[0]
+    images, labels, masks = images.cuda(), labels.cuda(), [m.cuda() for m in masks]
+
+    def inside(net, key):
+        flat = mw._banks[key].flat
+        lo, hi = flat.data_ptr(), flat.data_ptr() + 4 * flat.numel()
+        missing = [n for n, p in net.named_parameters() if p.grad is None]
+        loose = [n for n, p in net.named_parameters() if p.grad is not None and not (lo <= p.grad.data_ptr() < hi)]
+        return missing, loose
+
+    feats, _, _ = mw._d_phase(images, labels, labels.float(), masks, None)
+    assert inside(D, "d") == ([], []), inside(D, "d")
+    assert float(D.classification.bias.grad.abs().sum()) > 0.0
+    fake, z = mw._g_forward(images, labels.float(), masks, feats, None)
+    mw._g_rest(fake, z, labels, masks, feats, 0.1, 0.1)
+    assert inside(G, "g") == ([], []), inside(G, "g")
+
+
 def test_multi_gpu_code_path_in_a_one_rank_rccl_group():
     """Row e on one GPU: a real RCCL process group of ONE rank with the reducer kept live (single_rank_passthrough=False), so the
     side stream, the events, the in-place bucketed all-reduce of the flat gradient buffers, the group hooks of the eager
@@ -182,7 +211,10 @@ def test_multi_gpu_code_path_in_a_one_rank_rccl_group():
                 log.append((flat.data_ptr(), a, b))
                 return orig(flat, a, b)
             red.reduce_range = spy
+            loose_calls = []
+            red.reduce = lambda params, loose_calls=loose_calls: loose_calls.append(len(list(params)))
             got = run(red, graphed)
+            assert loose_calls == [], "gradients outside the flat buffers: %r" % loose_calls
             assert len(log) > 8, "no reduction was issued"
             for it in range(2):
                 for n in LOSS_NAMES:

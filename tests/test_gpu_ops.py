@@ -197,6 +197,35 @@ SPLITK_1X1_CASES = [(768, 512, 1, 20, 2, 2), (512, 512, 1, 20, 4, 4), (256, 256,
                     (128, 64, 1, 3, 3, 3), (512, 768, 1, 2, 2, 2)]
 
 
+@pytest.mark.parametrize("case", [(64, 64, 3, 2, 32, 32), (128, 96, 3, 2, 16, 16), (256, 64, 1, 2, 16, 16), (32, 48, 3, 3, 32, 32)])
+def test_wgrad_c_abi_without_workspace_fp32(case):
+    """Round-2 ADVICE (medium): sp_conv2d_wgrad has no workspace argument and sp_conv2d_wgrad_accum documents its scratch as
+    optional, but the deterministic fp32 mode used to reject every split plan without scratch.  Straight through the C ABI:
+    fp32, no workspace -> one ordered split per tile; result vs torch's conv2d weight gradient, twice bit-identical."""
+    import ctypes
+    from semantic_pyramid_for_image_generation_amd import _lib as L
+    cin, cout, k, n, h, w = case
+    x, dy = rnd(n, cin, h, w, seed=1), rnd(n, cout, h, w, seed=2)
+    xr = x.clone().requires_grad_(False)
+    wref = torch.zeros(cout, cin, k, k, requires_grad=True)
+    F.conv2d(xr, wref, padding=k // 2).backward(dy)
+    want = wref.grad.permute(0, 2, 3, 1).reshape(cout, k * k, cin)                  # [cout][tap][cin]
+    xd, dyd = dev(x, torch.float32), dev(dy, torch.float32)
+    outs = []
+    for entry in ("sp_conv2d_wgrad", "sp_conv2d_wgrad_accum"):
+        for rep in range(2):
+            dw = torch.zeros(cout, k * k, cin, device="cuda")
+            if entry == "sp_conv2d_wgrad":
+                dw.fill_(7.0)                                                         # the call zeroes dw itself
+                L.call(entry, ops.ptr(xd), ops.ptr(dyd), ops.ptr(dw), n, h, w, cin, cout, cout, k, L.SP_F32, ops.stream())
+            else:
+                L.call(entry, ops.ptr(xd), ops.ptr(dyd), ops.ptr(dw), None, None, 0, n, h, w, cin, cout, cout, k, L.SP_F32, ops.stream())
+            torch.cuda.synchronize()
+            close(dw, want, 2e-4, "%s %r" % (entry, case))
+            outs.append(dw)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[2], outs[3])
+
+
 @pytest.mark.parametrize("case", SPLITK_1X1_CASES)
 def test_conv1x1_splitk_kernel_bf16(case):
     """conv1x1_splitk_kernel (small maps: the four waves of a block split K, partial tiles meet in LDS) at the step's own deep
