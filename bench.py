@@ -35,9 +35,9 @@ sys.path.insert(0, ROOT)
 # (SURVEY.md section 8d): D-step 210.40 + G-step 199.34 GFLOP at channel_factor = 1.
 GFLOP_PER_IMAGE = {1: 409.74, 2: 197.75, 0.5: 1239.60}
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}      # dense MFMA peaks, MI355X_MICROARCH.md
-DOMINANT_KERNEL = "conv3x3_tall_kernel<bf16,2,8> (sp_conv2d_igemm, 3x3, Cout>64, 128 co x 8x32 px tiles)"
-DOMINANT_KERNEL_SYMBOL = "conv3x3_tall_kernel<bf16, 2, 8>"
-TRAFFIC_FILES = ("round2_hbm_traffic_per_kernel.json", "round1_hbm_traffic_per_kernel.json")
+DOMINANT_KERNEL = "conv3x3_pp_kernel<bf16,8> (sp_conv2d_igemm, 3x3, Cout>64, 128 co x 8x32 px tiles, ping-pong schedule)"
+DOMINANT_KERNEL_SYMBOL = "conv3x3_pp_kernel<bf16, 8"
+TRAFFIC_FILES = ("round3_hbm_traffic_per_kernel.json", "round2_hbm_traffic_per_kernel.json")
 
 
 def parse():
@@ -63,23 +63,53 @@ def parse():
 # ------------------------------------------------------------------------------------------------------------------
 # N > 1 without an outer launcher: spawn the ranks (the parent never initialises the GPU)
 # ------------------------------------------------------------------------------------------------------------------
-def spawn_ranks(n: int) -> int:
+def spawn_ranks(n: int, timeout_s: float = None) -> int:
+    """Starts the n ranks as fresh children (never re-executes a process that touched the GPU), relays rank 0's stdout, and
+    supervises them: when any rank exits non-zero, or nothing finishes within `timeout_s` (default: BENCH_RANK_TIMEOUT_S or
+    1800 s - a rank stuck at the rendezvous or in a collective whose partner died), the remaining ranks are terminated (then
+    killed) and the worst exit code is returned.  A hung multi-GPU run thus ends with a message instead of blocking the driver."""
     import socket
+    import tempfile
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("BENCH_RANK_TIMEOUT_S", "1800"))
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")             # rank 0's stdout (a pipe would need a reader thread to stay drained)
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(globals()["__file__"])] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        p.wait()
-        rc = rc or p.returncode
-    sys.stdout.write(out)
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
+    deadline = time.time() + timeout_s
+    rc, why = 0, None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            rc, why = bad[0][1], "rank %d exited with code %d" % bad[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() > deadline:
+            rc, why = 124, "no completion within %.0f s (ranks still running: %s)" % (timeout_s, [r for r, c in enumerate(codes) if c is None])
+            break
+        time.sleep(0.2)
+    if why is not None:
+        print("bench.py: %s; stopping the other ranks" % why, file=sys.stderr)
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()                            # exact PIDs this function started
+        t_end = time.time() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    out0.seek(0)
+    sys.stdout.write(out0.read())
     sys.stdout.flush()
     return rc
 
@@ -134,19 +164,25 @@ def cpu_baseline(cf, seconds_budget=30.0):
                       % (cf, results[2][1], results[2][2], results[20][1], results[20][2])}
 
 
-def recorded_traffic(symbol):
+def recorded_traffic(symbols):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, collected in
     separate runs of this script and reduced by profiles/extract_traffic.py); PMC counters cannot be read from inside the
-    process, so the committed summary is reported - None if it is missing."""
+    process, so the committed summary is reported WITH ITS PROVENANCE (file, sha256 of the file, the kernel name matched) -
+    (None, None) if it is missing."""
+    import hashlib
     for name in TRAFFIC_FILES:
+        path = os.path.join(ROOT, "profiles", name)
         try:
-            kernels = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
+            raw = open(path, "rb").read()
+            kernels = json.loads(raw)["kernels"]
         except (OSError, ValueError, KeyError):
             continue
-        for kname, rec in kernels.items():
-            if symbol in kname:
-                return rec["hbm_bytes_per_launch"]
-    return None
+        for symbol in symbols:
+            for kname, rec in kernels.items():
+                if symbol in kname:
+                    return rec["hbm_bytes_per_launch"], {"file": "profiles/" + name, "sha256_16": hashlib.sha256(raw).hexdigest()[:16],
+                                                         "kernel": kname[:96], "launches_profiled": rec.get("launches")}
+    return None, None
 
 
 def kernel_probe(step_fn, peak, steps=2):
@@ -238,6 +274,17 @@ class Job:
                 self.launch_mode = "hipgraph"
             except Exception as exc:                             # capture is plumbing: fall back to eager launches, say so
                 print("bench.py: HIP-graph capture failed (%s: %s); running eagerly" % (type(exc).__name__, exc), file=sys.stderr)
+            if world > 1:
+                # every rank must issue the SAME sequence of collectives: graph replay reduces the flat ranges after each graph,
+                # eager launches hand groups over from inside the backward - one rank falling back alone would pair mismatched
+                # buckets (or hang).  Agree on the minimum.
+                import torch.distributed as dist
+                ok = torch.tensor([1 if self.launch_mode == "hipgraph" else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok) == 0 and self.launch_mode == "hipgraph":
+                    print("bench.py: rank %d captured, another rank did not - all ranks run eagerly" % rank, file=sys.stderr)
+                    mw._graph_state = None
+                    self.step, self.launch_mode = eager_step, "eager"
 
     def timed(self, steps, warmup):
         import torch.distributed as dist
@@ -252,15 +299,36 @@ class Job:
         for _ in range(steps):
             out = self.step()
         torch.cuda.synchronize()
+        elapsed_local = time.perf_counter() - t0
         if self.world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        self.rank_elapsed = None
         if self.world > 1:
+            mine = torch.tensor([elapsed_local], dtype=torch.float64, device="cuda")
+            every = [torch.zeros_like(mine) for _ in range(self.world)]
+            dist.all_gather(every, mine)
+            self.rank_elapsed = [float(x) for x in every]           # each rank's own time to its last step (before the closing barrier)
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t)
         return elapsed, {k: float(v) for k, v in out.items() if k.startswith("loss")}
+
+    def comm_stats(self, steps=5):
+        """N > 1: a few extra steps with events around every collective (side stream) and every join (main stream):
+        all-reduce time of the D and the G gradients and the part of it the main stream actually waited for."""
+        red = self.mw.gradient_reducer
+        if red is None or not red.active():
+            return None
+        red.timing = True
+        try:
+            for _ in range(steps):
+                self.step()
+            st = red.stats()
+        finally:
+            red.timing = False
+        return st
 
     def close(self):
         self.mw = self.step = self.eager_step = None
@@ -321,6 +389,8 @@ def main():
         if world > 1:
             dist.barrier()
     launch_mode = job.launch_mode
+    comm = job.comm_stats() if world > 1 else None
+    rank_elapsed = job.rank_elapsed
     job.close()
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -345,13 +415,26 @@ def main():
                          "step_achieved": round(achieved, 2) if achieved else None,
                          "step_frac": round(achieved / peak, 4) if achieved else None},
         }
+        if world > 1:
+            # what a bad scaling curve needs to be diagnosed: the collectives' own time, what of it was NOT hidden, each rank's pace
+            line["multi_gpu"] = {
+                "per_rank_images_per_sec": [round(args.batch * args.steps / t, 2) for t in (rank_elapsed or [])],
+                "allreduce_ms_d": comm["d"]["allreduce_ms"] if comm and "d" in comm else None,
+                "allreduce_ms_g": comm["g"]["allreduce_ms"] if comm and "g" in comm else None,
+                "exposed_ms": round(sum(v["exposed_ms"] for v in comm.values()), 4) if comm else None,
+                "exposed_ms_d": comm["d"]["exposed_ms"] if comm and "d" in comm else None,
+                "exposed_ms_g": comm["g"]["exposed_ms"] if comm and "g" in comm else None,
+                "note": "rank 0's events over 5 extra steps: allreduce_ms = first collective start -> last end on the side stream; "
+                        "exposed_ms = main-stream wait at the joins (D's join sits behind the generator forward, G's before Adam(G))"}
         if probe is not None:
             families, dom, totals = probe
             line["roofline"].update({"achieved": totals["tflops"], "frac": round(totals["tflops"] / peak, 4),
                                      "conv_ms_per_step_eager": totals["ms_per_step"], "backward_tflops": totals["backward_tflops"],
                                      "backward_frac": round(totals["backward_tflops"] / peak, 4),
                                      "families": families, "dominant_kernel": dom})
-            line["roofline"]["traffic"] = recorded_traffic(DOMINANT_KERNEL_SYMBOL)
+            traffic, prov = recorded_traffic((DOMINANT_KERNEL_SYMBOL, "conv3x3_tall_kernel<bf16, 2, 8>"))
+            line["roofline"]["traffic"] = traffic
+            line["roofline"]["traffic_source"] = prov
         if world == 1 and not args.no_sub_records:
             if args.dtype == "bf16":
                 line["parity_mode"] = sub_record(cf, args.batch, "f32", dev, 8, 3, not args.no_graphs)
@@ -360,6 +443,11 @@ def main():
             if args.batch != 32:
                 line["batch32"] = sub_record(cf, 32, args.dtype, dev, 15, 5, not args.no_graphs)
                 line["batch32"]["note"] = "BASELINE.json config 2: one MI355X, batch 32"
+        if world == 1 and not args.no_sub_records:
+            # DVFS-steady throughput: the headline window (K steps) can be shorter than the clock governor's settling time
+            n_sus = max(args.steps, int(6.0 / max(ms * 1e-3, 1e-4)))
+            line["sustained"] = sub_record(cf, args.batch, args.dtype, dev, n_sus, 5, not args.no_graphs)
+            line["sustained"]["note"] = ">= 6 s of back-to-back steps (power / clock steady state)"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cf)
         flush_c_stdio()

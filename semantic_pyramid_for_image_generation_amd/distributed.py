@@ -33,6 +33,10 @@ class GradientReducer:
         self._side = None
         self._pending = 0
         self.log: List[Tuple[int, int]] = []       # (start, stop) of every range reduced since the last join (tests)
+        # timing (bench.py, N > 1): events around every collective on the side stream and around every join on the main stream
+        self.timing = False
+        self._marks: list = []                     # (first event, last event) pairs of the collectives since the last join
+        self._joins: list = []                     # (tag, marks, event before the join's wait, event after it)
 
     def world_size(self) -> int:
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
@@ -60,21 +64,51 @@ class GradientReducer:
         ev.record()                                   # the producers of this range, enqueued so far on the current stream
         self._side.wait_event(ev)
         with torch.cuda.stream(self._side):
+            if self.timing:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
             work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             work.wait()                               # side stream waits for the collective; the host does not
             view.mul_(1.0 / ws)
+            if self.timing:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                self._marks.append((e0, e1))
         self._pending += 1
 
     def reduce_flat(self, flat: torch.Tensor, ranges: Sequence[Tuple[int, int]]) -> None:
         for a, b in ranges:
             self.reduce_range(flat, a, b)
 
-    def join(self) -> None:
+    def join(self, tag: str = "") -> None:
         """The current stream waits for every reduction enqueued so far."""
         if self._pending:
+            if self.timing:
+                m0 = torch.cuda.Event(enable_timing=True)
+                m0.record()
             torch.cuda.current_stream().wait_stream(self._side)      # `flat` is persistent: no allocator hand-over to record
+            if self.timing:
+                m1 = torch.cuda.Event(enable_timing=True)
+                m1.record()
+                self._joins.append((tag, self._marks, m0, m1))
+                self._marks = []
             self._pending = 0
         self.log = []
+
+    def stats(self) -> dict:
+        """Means over the joins recorded while `timing` was on, per tag: `allreduce_ms` = first collective's start to the last
+        one's end on the side stream (scaling included), `exposed_ms` = how long the main stream actually waited at the join
+        (what the overlap did not hide).  Synchronises."""
+        torch.cuda.synchronize()
+        acc = {}
+        for tag, marks, m0, m1 in self._joins:
+            a = acc.setdefault(tag, [0.0, 0.0, 0])
+            if marks:
+                a[0] += marks[0][0].elapsed_time(marks[-1][1])
+            a[1] += m0.elapsed_time(m1)
+            a[2] += 1
+        self._joins = []
+        return {tag: {"allreduce_ms": round(v[0] / v[2], 4), "exposed_ms": round(v[1] / v[2], 4), "joins": v[2]} for tag, v in acc.items() if v[2]}
 
     # -------------------------------------------------------------------------------------------- per-parameter (fallback)
     def reduce(self, params: Sequence[torch.Tensor]) -> None:

@@ -21,7 +21,7 @@ from typing import Dict, Optional, Union
 import torch
 import torch.nn as nn
 
-from . import misc, ops
+from . import misc, ops, profiling
 from .config import CFG
 from .lossfunction import DiversityLoss, LSGANDiscriminatorLoss, LSGANGeneratorLoss, SemanticReconstructionLoss
 from .models import VGG16, Discriminator, Generator
@@ -146,9 +146,9 @@ class ModelWrapper(object):
         if loose:
             red.reduce(loose)
 
-    def _join_reduce(self) -> None:
+    def _join_reduce(self, tag: str = "") -> None:
         if self.gradient_reducer is not None:
-            self.gradient_reducer.join()
+            self.gradient_reducer.join(tag)
 
     # ------------------------------------------------------------------------------------------
     def _d_phase(self, images_real, labels, labels_f, masks, noise_d):
@@ -207,15 +207,20 @@ class ModelWrapper(object):
         Order of work (results identical to the reference's order): D phase; [D gradients -> side stream]; generator forward of
         the G phase (independent of D); join; Adam(D); rest of the G phase; [G gradients -> side stream]; join; Adam(G)."""
         labels_f = labels.float()
-        features_real, loss_d_real, loss_d_fake = self._d_phase(images_real, labels, labels_f, masks, noise_d)
-        self._start_reduce("d", self._d_params, eager=True)
-        images_fake, noise_g = self._g_forward(images_real, labels_f, masks, features_real, noise_g)
-        self._join_reduce()
-        self.discriminator_optimizer.step()
-        loss_g, loss_rec, loss_div = self._g_rest(images_fake, noise_g, labels, masks, features_real, w_rec, w_div)
-        self._start_reduce("g", self._g_params, eager=True)
-        self._join_reduce()
-        self.generator_optimizer.step()
+        with profiling.range("D phase"):
+            features_real, loss_d_real, loss_d_fake = self._d_phase(images_real, labels, labels_f, masks, noise_d)
+            self._start_reduce("d", self._d_params, eager=True)
+        with profiling.range("G forward"):
+            images_fake, noise_g = self._g_forward(images_real, labels_f, masks, features_real, noise_g)
+        with profiling.range("Adam(D)"):
+            self._join_reduce("d")
+            self.discriminator_optimizer.step()
+        with profiling.range("G rest"):
+            loss_g, loss_rec, loss_div = self._g_rest(images_fake, noise_g, labels, masks, features_real, w_rec, w_div)
+            self._start_reduce("g", self._g_params, eager=True)
+        with profiling.range("Adam(G)"):
+            self._join_reduce("g")
+            self.generator_optimizer.step()
         self.iterations += 1
         return {"loss_discriminator_real": loss_d_real.detach(), "loss_discriminator_fake": loss_d_fake.detach(),
                 "loss_generator": loss_g.detach(), "loss_generator_semantic_reconstruction": loss_rec.detach().reshape(()),
@@ -284,25 +289,30 @@ class ModelWrapper(object):
         if masks is not None and masks is not st["masks"]:
             for dst, src in zip(st["masks"], masks):
                 dst.copy_(src, non_blocking=True)
-        st["gd"].replay()
-        for p, g in zip(self._d_params, st["d_grads"]):
-            p.grad = g
-        self._start_reduce("d", self._d_params, eager=False)
+        with profiling.range("D phase"):
+            st["gd"].replay()
+            for p, g in zip(self._d_params, st["d_grads"]):
+                p.grad = g
+            self._start_reduce("d", self._d_params, eager=False)
         if noise_g is None:
             st["noise_g"].normal_()
         else:
             st["noise_g"].copy_(noise_g)
-        st["gf"].replay()                                       # generator forward: overlaps the D gradient all-reduce
-        self._join_reduce()
-        self.discriminator_optimizer.step()
-        st["gg"].replay()
-        for p, g in zip(self._g_params, st["g_grads"]):
-            p.grad = g
-        for p in self._d_params:
-            p.grad = None
-        self._start_reduce("g", self._g_params, eager=False)
-        self._join_reduce()
-        self.generator_optimizer.step()
+        with profiling.range("G forward"):
+            st["gf"].replay()                                   # generator forward: overlaps the D gradient all-reduce
+        with profiling.range("Adam(D)"):
+            self._join_reduce("d")
+            self.discriminator_optimizer.step()
+        with profiling.range("G rest"):
+            st["gg"].replay()
+            for p, g in zip(self._g_params, st["g_grads"]):
+                p.grad = g
+            for p in self._d_params:
+                p.grad = None
+            self._start_reduce("g", self._g_params, eager=False)
+        with profiling.range("Adam(G)"):
+            self._join_reduce("g")
+            self.generator_optimizer.step()
         self.iterations += 1
         return st["out"]
 
