@@ -2,7 +2,8 @@
 reference's own ModelWrapper.train() loop (tests/golden/, see make_golden.py) and against the CPU oracle.
 
 Tolerances (north_star): <= 1e-3 relative on generator pixels and loss scalars in fp32 mode.  The bf16 mode
-(bf16 storage, bf16 MFMA, fp32 accumulate) is held to 5e-2 on losses and 8e-2 of the pixel range."""
+(bf16 storage, bf16 MFMA, fp32 accumulate) is held to 2x its MEASURED error against the same goldens (BF16_MEASURED below:
+losses ~1.3e-3 relative, pixels 3.3e-2 absolute at the worst of 4096 samples, 6.3e-3 rms)."""
 import numpy as np
 import pytest
 import torch
@@ -117,20 +118,44 @@ def test_fp32_step_is_bit_reproducible():
         assert torch.equal(d0[k], d1[k]), k
 
 
-@pytest.mark.parametrize("tag", ["step_cf1_b2_seed0", "step_cf4_b4_seed1"])
-def test_train_step_bf16_restated_tolerance(tag):
-    """The THROUGHPUT mode (bf16 storage + bf16 MFMA, fp32 accumulate: what bench.py times) against the reference goldens, incl.
-    the benchmark's own channel_factor = 1.  Restated tolerance (bf16 has 8 mantissa bits; the reference is fp32 end to end):
-    losses 5e-2 relative, pixels 8e-2 of the (-1, 1) range at the worst sample and 2e-2 rms."""
+def bf16_step_errors(tag, graphed=False):
+    """Measured errors of the bf16 throughput mode against the reference goldens of `tag`: worst relative loss error, worst
+    absolute pixel error and pixel rms over the recorded samples, per iteration (shared with bench.py's bf16_parity record)."""
     meta, arr, G, D, outs = run_steps(tag, torch.bfloat16)
     pix_idx = gu.fixed_indices(meta["batch_size"] * 3 * 256 * 256, gu.N_PIX, 0)
+    rec = {"loss_rel": [], "pixel_max": [], "pixel_rms": []}
     for it, out in enumerate(outs):
-        for n in LOSS_NAMES:
-            assert float(out[n]) == pytest.approx(meta[n][it], rel=5e-2, abs=2e-3), (n, it)
+        rec["loss_rel"].append(max(abs(float(out[n]) - meta[n][it]) / max(abs(meta[n][it]), 2e-2) for n in LOSS_NAMES))
         fake = out["images_fake"].float().cpu().contiguous().flatten()[pix_idx].numpy()
         ref = arr["fake_samples"][2 * it + 1]
-        assert np.abs(fake - ref).max() <= 8e-2 * 2.0, ("pixels", it)
-        assert np.sqrt(np.mean((fake - ref) ** 2)) <= 2e-2, ("pixel rms", it)
+        rec["pixel_max"].append(float(np.abs(fake - ref).max()))
+        rec["pixel_rms"].append(float(np.sqrt(np.mean((fake - ref) ** 2))))
+    return rec
+
+
+# measured on MI355X (round 3, printed by the test below; bf16 storage + bf16 MFMA, fp32 accumulate, vs the fp32 reference):
+#   tag                 worst loss error (relative, floor 2e-2)   worst pixel error   pixel rms
+BF16_MEASURED = {"step_cf1_b2_seed0": (1.3e-3, 3.3e-2, 6.3e-3), "step_cf4_b4_seed1": (1.0e-3, 3.4e-2, 6.3e-3)}
+
+
+@pytest.mark.parametrize("tag", ["step_cf1_b2_seed0", "step_cf4_b4_seed1"])
+def test_train_step_bf16_restated_tolerance(tag):
+    """The THROUGHPUT mode (what bench.py times) against the reference goldens, incl. the benchmark's own channel_factor = 1.
+    The bound is 2x the MEASURED error (BF16_MEASURED above; the measurement is printed and written to
+    gpurun_out/bf16_parity_<tag>.json on every run), not a guess: bf16 has 8 mantissa bits, the reference is fp32 end to end."""
+    import json
+    import os
+    rec = bf16_step_errors(tag)
+    print("bf16 vs reference goldens, %s: %s" % (tag, json.dumps(rec)))
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        json.dump(rec, open(os.path.join("gpurun_out", "bf16_parity_%s.json" % tag), "w"))
+    except OSError:
+        pass
+    loss, pix, rms = BF16_MEASURED[tag]
+    assert max(rec["loss_rel"]) <= 2 * loss, rec
+    assert max(rec["pixel_max"]) <= 2 * pix, rec
+    assert max(rec["pixel_rms"]) <= 2 * rms, rec
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
@@ -189,11 +214,9 @@ def test_full_size_step_properties_bf16():
     assert changed == {"main_path.1.masked_feature_mapping.weight_orig"}, changed
 
 
-def test_graphed_step_matches_eager_step():
-    """ModelWrapper.capture_graphs / train_step_graphed: same state, same RNG seed -> the same losses as the eager step
-    (fp32, cf=4: differences only from the order of fp32 atomics)."""
-    meta, arr = gu.load("step_cf4_b4_seed1")
-    ops.set_compute_dtype(torch.float32)
+def _eager_vs_graphed(dtype, tag):
+    meta, arr = gu.load(tag)
+    ops.set_compute_dtype(dtype)
     outs = []
     for graphed in (False, True):
         G, D, V = build(meta)
@@ -211,9 +234,33 @@ def test_graphed_step_matches_eager_step():
         out = None
         for _ in range(2):
             out = mw.train_step_graphed(images, labels, masks) if graphed else mw.train_step(images, labels, masks)
-        outs.append({k: float(v) for k, v in out.items() if k.startswith("loss")})
-    for k in outs[0]:
-        assert outs[1][k] == pytest.approx(outs[0][k], rel=2e-3, abs=1e-6), (k, outs)
+        rec = {k: float(v) for k, v in out.items() if k.startswith("loss")}
+        rec["pixels"] = out["images_fake"].detach().float().clone()
+        rec["G"] = {k: v.detach().clone() for k, v in G.state_dict().items()}
+        outs.append(rec)
+    return outs
+
+
+def test_graphed_step_matches_eager_step():
+    """ModelWrapper.capture_graphs / train_step_graphed (the launch mode bench.py times and train() switches to): same state,
+    same RNG seed.  fp32 parity mode: every reduction runs in a fixed order, so replay and eager launches must agree EXACTLY -
+    losses, pixels and the generator's state after three steps (round 2 compared with rel=2e-3, a leftover of round 1's
+    atomics)."""
+    eager, graphed = _eager_vs_graphed(torch.float32, "step_cf4_b4_seed1")
+    for k in LOSS_NAMES:
+        assert graphed[k] == eager[k], (k, graphed[k], eager[k])
+    assert torch.equal(graphed["pixels"], eager["pixels"])
+    for k in eager["G"]:
+        assert torch.equal(graphed["G"][k], eager["G"][k]), k
+
+
+def test_graphed_step_matches_eager_step_bf16():
+    """The same in the bf16 throughput mode at the benchmark's channel_factor = 1: the small-map weight gradients merge through
+    fp32 atomics there, so two runs differ by summation order only - losses to 2e-2 relative, pixels 2e-2 of the range."""
+    eager, graphed = _eager_vs_graphed(torch.bfloat16, "step_cf1_b2_seed0")
+    for k in LOSS_NAMES:
+        assert graphed[k] == pytest.approx(eager[k], rel=2e-2, abs=1e-4), (k, graphed[k], eager[k])
+    assert float((graphed["pixels"] - eager["pixels"]).abs().max()) <= 2e-2 * 2.0
 
 
 def test_eval_mode_generator_forward_vs_oracle():
