@@ -351,6 +351,50 @@ def sub_record(cf, batch, dtype_name, dev, steps, warmup, use_graphs):
     return rec
 
 
+def bf16_parity_record(dev, tag="step_cf1_b2_seed0"):
+    """The benchmarked (bf16) mode against the committed reference goldens of the two-iteration loop (tests/golden/<tag>: loss
+    scalars and 4096 generator-pixel samples recorded from the unmodified reference, tests/golden/make_golden.py): the MEASURED
+    errors of this very build, so that the throughput figure and "matches the reference" are statements about one program.
+    tests/test_gpu_step.py::test_train_step_bf16_restated_tolerance asserts 2x these figures."""
+    import json as _json
+    import numpy as np
+    import semantic_pyramid_for_image_generation_amd as sp
+    from semantic_pyramid_for_image_generation_amd import ops, params
+    gold = os.path.join(ROOT, "tests", "golden")
+    if gold not in sys.path:
+        sys.path.insert(0, gold)
+    import make_golden                                           # committed generator of the golden batches (data only)
+    meta = _json.load(open(os.path.join(gold, tag + ".json")))
+    arr = dict(np.load(os.path.join(gold, tag + ".npz")))
+    ops.set_compute_dtype(torch.bfloat16)
+    G, D, V = sp.Generator(channels_factor=meta["cf"]), sp.Discriminator(channel_factor=meta["cf"]), sp.VGG16()
+    for net, seed in ((G, meta["seed"]), (D, meta["seed"] + 1), (V, meta["seed"] + 2)):
+        net.load_state_dict(params.synth_state_dict(net.state_dict(), seed))
+    G.to(dev).train(); D.to(dev).train(); V.to(dev).eval()
+    mw = sp.ModelWrapper(G, D, None, None, vgg16=V, generator_optimizer=torch.optim.Adam(G.parameters(), lr=meta["lr"]),
+                         discriminator_optimizer=torch.optim.Adam(D.parameters(), lr=meta["lr"]), save_data_path=None)
+    noise = torch.from_numpy(arr["noise"]).to(dev)
+    names = ("loss_discriminator_real", "loss_discriminator_fake", "loss_generator", "loss_generator_semantic_reconstruction",
+             "loss_generator_diversity")
+    g = torch.Generator().manual_seed(977)
+    idx = torch.randint(0, meta["batch_size"] * 3 * 256 * 256, (4096,), generator=g)
+    rec = {"loss_rel": [], "pixel_max": [], "pixel_rms": []}
+    for it, (images, labels, masks) in enumerate(make_golden.golden_batches(meta["batch_size"], meta["seed"])):
+        out = mw.train_step(images.to(dev), labels.to(dev), [m.to(dev) for m in masks], noise_d=noise[2 * it], noise_g=noise[2 * it + 1])
+        rec["loss_rel"].append(max(abs(float(out[n]) - meta[n][it]) / max(abs(meta[n][it]), 2e-2) for n in names))
+        fake = out["images_fake"].float().cpu().contiguous().flatten()[idx].numpy()
+        ref = arr["fake_samples"][2 * it + 1]
+        rec["pixel_max"].append(float(np.abs(fake - ref).max()))
+        rec["pixel_rms"].append(float(np.sqrt(np.mean((fake - ref) ** 2))))
+    del mw
+    gc.collect()
+    torch.cuda.empty_cache()
+    return {"against": "reference goldens tests/golden/%s (cf=%s, batch %d, 2 iterations of the reference's own loop)" % (tag, meta["cf"], meta["batch_size"]),
+            "worst_loss_rel_err": round(max(rec["loss_rel"]), 6), "worst_pixel_abs_err": round(max(rec["pixel_max"]), 5),
+            "pixel_rms_err": round(max(rec["pixel_rms"]), 5), "fp32_mode_bound": 1e-3,
+            "note": "bf16 storage + bf16 MFMA + fp32 accumulate vs the fp32 reference; the fp32 parity mode meets 1e-3 (parity_mode record)"}
+
+
 def flush_c_stdio():
     """RCCL writes its banner with C stdio, which is fully buffered on a pipe and would otherwise surface after the JSON line."""
     import ctypes
@@ -443,6 +487,11 @@ def main():
             if args.batch != 32:
                 line["batch32"] = sub_record(cf, 32, args.dtype, dev, 15, 5, not args.no_graphs)
                 line["batch32"]["note"] = "BASELINE.json config 2: one MI355X, batch 32"
+        if world == 1 and not args.no_sub_records and args.dtype == "bf16" and cf == 1:
+            try:
+                line["bf16_parity"] = bf16_parity_record(dev)
+            except Exception as exc:                             # a reported figure, not the thing measured: never sink the line
+                line["bf16_parity"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         if world == 1 and not args.no_sub_records:
             # DVFS-steady throughput: the headline window (K steps) can be shorter than the clock governor's settling time
             n_sus = max(args.steps, int(6.0 / max(ms * 1e-3, 1e-4)))

@@ -350,6 +350,16 @@ int sp_div_loss_fwd(const void* img, int64_t half_elems, const float* z, int64_t
 int sp_div_loss_bwd(const void* img, int64_t half_elems, const float* fwd_out2, const float* gout, void* dimg,
                     int32_t dtype, sp_stream_t stream);
 
+/* A batch of training masks generated on the device: misc.get_masks_for_training
+ * (/root/reference/misc.py:13-68) for every sample of the batch in one launch - stage ~ choice([0..6, 0, 1]) counted from the deep
+ * end, with probability p_random_mask (reference: 0.3) and 0 < stage < 6 a 0/1 shape map on the next finer level expanded
+ * nearest-neighbour to all finer levels, everything deeper than the stage zero, exact 0.0f / 1.0f.  The seven outputs are the
+ * reference's list order, fp32, [batch][1][S][S] contiguous / [batch][4096] / [batch][365].  All randomness is integer
+ * arithmetic on splitmix64(seed, sample, draw): the same (seed, batch) gives the same masks on every device, and the oracle
+ * restates the generator bit for bit (tests/test_gpu_next_rows.py). */
+int sp_training_masks(float* m128, float* m64, float* m32, float* m16, float* m8, float* m4096, float* m365,
+                      int32_t batch, uint64_t seed, float p_random_mask, sp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Multi-tensor Adam: torch.optim.Adam (main.py:64-65; .step() at model_wrapper.py:162,190) for every parameter of
  * a network in one launch.  The host splits the fp32 tensors into chunks (<= 65536 elements each); step_size =

@@ -446,3 +446,67 @@ def vgg16_layout(classes=365):
 def layout_template(spec) -> Dict[str, torch.Tensor]:
     """Zero tensors with the layout's shapes/dtypes (meta-like template for params.synth_state_dict)."""
     return {k: torch.empty(shape, dtype=dt) for k, (shape, dt) in spec.items()}
+
+
+# --------------------------------------------------------------------------------------
+# training masks (row f1): restatement of csrc/eltwise.hip::training_masks_kernel, i.e. of
+# misc.get_masks_for_training (/root/reference/misc.py:13-68) on a counter-based integer generator
+# --------------------------------------------------------------------------------------
+_M64 = (1 << 64) - 1
+
+
+def _mix64(z: int) -> int:
+    z = (z + 0x9E3779B97F4A7C15) & _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+def _draw(seed: int, sample: int, k: int) -> int:
+    return _mix64((_mix64((seed ^ (sample << 32)) & _M64) + k) & _M64)
+
+
+def training_mask_decisions(batch: int, seed: int, p_random_mask: float = 0.3):
+    """(stage, spatial) of every sample - the decisions of misc.py:28-34."""
+    tab = [0, 1, 2, 3, 4, 5, 6, 0, 1]
+    thresh = int(float(torch.tensor(p_random_mask, dtype=torch.float32)) * 16777216.0)
+    out = []
+    for b in range(batch):
+        stage = tab[_draw(seed, b, 0) % 9]
+        spatial = (_draw(seed, b, 1) >> 40) < thresh and 0 < stage < 6
+        out.append((stage, spatial))
+    return out
+
+
+def training_masks(batch: int, seed: int, p_random_mask: float = 0.3) -> List[torch.Tensor]:
+    """The seven masks (reference list order: 128^2 ... 365) the device generator must reproduce bit for bit."""
+    sides = [1, 1, 8, 16, 32, 64, 128]
+    numel = [365, 4096, 64, 256, 1024, 4096, 16384]
+    levels = [torch.zeros(batch, n) for n in numel]
+    for b, (stage, spatial) in enumerate(training_mask_decisions(batch, seed, p_random_mask)):
+        base = sides[min(stage + 1, 6)]
+        lo = min(8, base // 2)
+        rects = []
+        if spatial:
+            for k in range(1 + _draw(seed, b, 2) % 4):
+                h = lo + _draw(seed, b, 3 + 4 * k) % (base - lo + 1)
+                w = lo + _draw(seed, b, 4 + 4 * k) % (base - lo + 1)
+                y0 = _draw(seed, b, 5 + 4 * k) % (base - h + 1)
+                x0 = _draw(seed, b, 6 + 4 * k) % (base - w + 1)
+                rects.append((y0, x0, h, w))
+        for idx in range(7):
+            if idx == stage:
+                levels[idx][b] = 1.0
+            elif idx > stage and spatial:
+                side = sides[idx]
+                shape_map = torch.ones(base, base)
+                for y0, x0, h, w in rects:
+                    shape_map[y0:y0 + h, x0:x0 + w] = 0.0
+                src = (torch.arange(side) * base) // side
+                levels[idx][b] = shape_map[src][:, src].reshape(-1)
+    out = []
+    for idx in (6, 5, 4, 3, 2):
+        s = sides[idx]
+        out.append(levels[idx].reshape(batch, 1, s, s))
+    out += [levels[1], levels[0]]
+    return out

@@ -56,7 +56,7 @@ class SpSnBwdLayer(ctypes.Structure):
 
 
 _CTYPE = {"int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "double": ctypes.c_double, "int": ctypes.c_int,
-          "sp_stream_t": ctypes.c_void_p}
+          "sp_stream_t": ctypes.c_void_p, "uint64_t": ctypes.c_uint64}
 
 
 def parse_header(path: str = HEADER) -> Dict[str, Tuple[object, List[object]]]:

@@ -372,3 +372,78 @@ extern "C" int sp_channel_sum(const void* x, int32_t ld, int64_t pixels, int32_t
     SP_LAUNCH_CHECK();
     return SP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// Training masks on the device (replaces misc.get_masks_for_training, /root/reference/misc.py:13-68, which
+// runs per sample in DataLoader workers).  One block per sample; all randomness is INTEGER arithmetic on a counter-based
+// generator (splitmix64 of (seed, sample, draw index)), so oracle/sempyr_oracle.py restates it bit for bit:
+//   draw 0: stage = [0,1,2,3,4,5,6,0,1][r % 9]                (misc.py:28: random.choice(list(range(7)) + [0, 1]), deep end first)
+//   draw 1: spatial = (r >> 40) < p_random * 2^24  and  0 < stage < 6        (misc.py:32-34)
+//   draw 2: number of shapes 1 + r % 4                                          (misc.py:38-39: min_shapes 1, max_shapes 4)
+//   draws 3 + 4k .. 6 + 4k (shape k): h = lo + r % (base - lo + 1), w likewise, y0 = r % (base - h + 1), x0 likewise, on the
+//            level just finer than the stage (side `base`, lo = min(8, base / 2): misc.py:37-41); axis-aligned rectangles
+//            stand in for skimage's random shapes (not available offline; the mask contract - zeros inside shapes, ones
+//            outside, nearest-neighbour expansion to every finer level, misc.py:45,55 - is the reference's)
+// Level idx (0 = the 365-vector ... 6 = 128 x 128): ones where idx == stage, zeros where idx < stage; idx > stage: zeros, or
+// with `spatial` the shape map read through the nearest-neighbour index i * base / side.  Values are exact 0.0f / 1.0f.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long sp_mix64(unsigned long long z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ unsigned long long sp_draw(unsigned long long seed, unsigned sample, unsigned k) {
+    return sp_mix64(sp_mix64(seed ^ ((unsigned long long)sample << 32)) + k);
+}
+
+struct sp_mask_ptrs { float* m[7]; };          // list order of the reference: 128^2, 64^2, 32^2, 16^2, 8^2, 4096, 365
+
+__global__ __launch_bounds__(256) void training_masks_kernel(sp_mask_ptrs out, unsigned long long seed, unsigned thresh24) {
+    const unsigned b = blockIdx.x;
+    const int stage_tab[9] = {0, 1, 2, 3, 4, 5, 6, 0, 1};
+    const int side_of[7] = {1, 1, 8, 16, 32, 64, 128};         // side of level idx (counted from the deep end); 0 / 1 are vectors
+    const int numel_of[7] = {365, 4096, 64, 256, 1024, 4096, 16384};
+    const int stage = stage_tab[sp_draw(seed, b, 0) % 9];
+    const bool spatial = (unsigned)(sp_draw(seed, b, 1) >> 40) < thresh24 && stage > 0 && stage < 6;
+    const int base = side_of[stage + 1 > 6 ? 6 : stage + 1];
+    const int lo = base / 2 < 8 ? base / 2 : 8;
+    int nrect = 0, ry[4], rx[4], rh[4], rw[4];
+    if (spatial) {
+        nrect = 1 + (int)(sp_draw(seed, b, 2) % 4);
+        for (int k = 0; k < 4; ++k) {
+            rh[k] = lo + (int)(sp_draw(seed, b, 3 + 4 * k) % (unsigned)(base - lo + 1));
+            rw[k] = lo + (int)(sp_draw(seed, b, 4 + 4 * k) % (unsigned)(base - lo + 1));
+            ry[k] = (int)(sp_draw(seed, b, 5 + 4 * k) % (unsigned)(base - rh[k] + 1));
+            rx[k] = (int)(sp_draw(seed, b, 6 + 4 * k) % (unsigned)(base - rw[k] + 1));
+        }
+    }
+    for (int idx = 0; idx < 7; ++idx) {
+        float* dst = out.m[6 - idx] + (long)b * numel_of[idx];
+        const int n = numel_of[idx], side = side_of[idx];
+        if (idx <= stage || !spatial) {
+            const float v = idx == stage ? 1.f : 0.f;
+            for (int i = threadIdx.x; i < n; i += 256) dst[i] = v;
+            continue;
+        }
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int y = (i / side) * base / side, x = (i % side) * base / side;
+            bool hit = false;
+            for (int k = 0; k < nrect; ++k) hit |= y >= ry[k] && y < ry[k] + rh[k] && x >= rx[k] && x < rx[k] + rw[k];
+            dst[i] = hit ? 0.f : 1.f;
+        }
+    }
+}
+
+extern "C" int sp_training_masks(float* m128, float* m64, float* m32, float* m16, float* m8, float* m4096, float* m365,
+                                 int32_t batch, uint64_t seed, float p_random_mask, sp_stream_t stream) {
+    SP_CHECK_ARG(m128 && m64 && m32 && m16 && m8 && m4096 && m365 && batch > 0, "sp_training_masks: bad args");
+    SP_CHECK_ARG(p_random_mask >= 0.f && p_random_mask <= 1.f, "sp_training_masks: p_random_mask outside [0, 1]");
+    sp_mask_ptrs o;
+    o.m[0] = m128; o.m[1] = m64; o.m[2] = m32; o.m[3] = m16; o.m[4] = m8; o.m[5] = m4096; o.m[6] = m365;
+    const unsigned thresh = (unsigned)((double)p_random_mask * 16777216.0);
+    hipLaunchKernelGGL(training_masks_kernel, dim3((unsigned)batch), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), o,
+                       (unsigned long long)seed, thresh);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}

@@ -65,45 +65,32 @@ def training_masks(g: torch.Generator, p_random_mask: float = 0.3) -> List[torch
     return masks_for_stage(stage, spatial)
 
 
+_MASK_STEP = {}
+
+
 def training_masks_device(batch_size: int, device, generator: Optional[torch.Generator] = None,
-                          p_random_mask: float = 0.3) -> List[torch.Tensor]:
-    """A whole batch of training masks generated ON THE DEVICE with tensor ops: the reference builds them
-    per sample in DataLoader workers (misc.py:13-68), which cannot feed several hundred images per second.  Same contract
-    as training_masks(): stage ~ choice([0..6, 0, 1]) counted from the deep end; with probability p_random_mask and
-    0 < stage < 6 a 0/1 map of 1-4 zero rectangles at the level just finer than the stage is nearest-upsampled to all finer
-    levels; everything deeper than the stage is zero; values are exact 0.0 / 1.0."""
+                          p_random_mask: float = 0.3, seed: Optional[int] = None) -> List[torch.Tensor]:
+    """A whole batch of training masks generated ON THE DEVICE by one kernel launch (sp_training_masks): the
+    reference builds them per sample in DataLoader workers (misc.py:13-68), which cannot feed a thousand images per second.
+    Same contract as training_masks(): stage ~ choice([0..6, 0, 1]) counted from the deep end; with probability p_random_mask
+    and 0 < stage < 6 a 0/1 map of 1-4 zero rectangles at the level just finer than the stage is nearest-upsampled to all finer
+    levels; everything deeper than the stage is zero; values are exact 0.0 / 1.0.  ``seed``: the 64-bit seed of this batch
+    (the generator is counter based: no device RNG state, no host sync); without it the seed is ``generator.initial_seed()``
+    (or 0) plus a per-generator call counter."""
+    import ctypes
+    from . import _lib as L
+    from . import ops
     dev = torch.device(device)
-    kw = dict(device=dev, generator=generator)
-    choices = torch.tensor(list(range(7)) + [0, 1], device=dev)
-    stage = choices[torch.randint(0, 9, (batch_size,), **kw)]                       # (B,), counted from the deep end
-    spatial = (torch.rand(batch_size, **kw) < p_random_mask) & (stage > 0) & (stage < 6)
-    rev = tuple(reversed(MASK_SHAPES))                                              # index = stage
-    sizes = torch.tensor([shp[-1] if len(shp) == 3 else 1 for shp in rev], device=dev)
-    base = sizes[(stage + 1).clamp(max=6)]                                          # side of the level the rectangles live on
-    lo = torch.minimum(torch.full_like(base, 8), base // 2)
-    nrect = torch.randint(1, 5, (batch_size,), **kw)
-    u = torch.rand(batch_size, 4, 4, **kw)                                          # (sample, rectangle, [h, w, y, x])
-    h = lo[:, None] + (u[:, :, 0] * (base - lo + 1)[:, None]).long().clamp(max=(base - lo)[:, None])
-    w = lo[:, None] + (u[:, :, 1] * (base - lo + 1)[:, None]).long().clamp(max=(base - lo)[:, None])
-    y0 = (u[:, :, 2] * (base[:, None] - h + 1)).long().clamp(max=base[:, None] - h)
-    x0 = (u[:, :, 3] * (base[:, None] - w + 1)).long().clamp(max=base[:, None] - w)
-    live = torch.arange(4, device=dev)[None, :] < nrect[:, None]                    # (B, 4) rectangles in use
-    out = []
-    for idx, shp in enumerate(rev):
-        is_stage = (stage == idx).float()
-        if len(shp) == 1:
-            out.append(is_stage[:, None].expand(batch_size, shp[0]).contiguous())
-            continue
-        side = shp[-1]
-        # nearest-neighbour upsampling from `base` to `side`: output pixel i reads source pixel i * base // side
-        src = (torch.arange(side, device=dev)[None, :] * base[:, None]) // side     # (B, side)
-        in_y = (src[:, None, :] >= y0[:, :, None]) & (src[:, None, :] < (y0 + h)[:, :, None])      # (B, 4, side)
-        in_x = (src[:, None, :] >= x0[:, :, None]) & (src[:, None, :] < (x0 + w)[:, :, None])
-        hit = (in_y[:, :, :, None] & in_x[:, :, None, :] & live[:, :, None, None]).any(dim=1)       # (B, side, side)
-        finer = (spatial & (idx > stage)).float()[:, None, None]
-        m = is_stage[:, None, None] + finer * (1.0 - hit.float())
-        out.append(m[:, None].contiguous())
-    out.reverse()
+    if dev.type != "cuda":
+        raise L.SempyrError("training_masks_device: needs a CUDA/HIP device (no CPU path; tests use the oracle's restatement)")
+    if seed is None:
+        key = id(generator) if generator is not None else 0
+        base = int(generator.initial_seed()) if generator is not None else 0
+        step = _MASK_STEP.get(key, 0)
+        _MASK_STEP[key] = step + 1
+        seed = (base * 0x9E3779B97F4A7C15 + step) & ((1 << 64) - 1)
+    out = [torch.empty((batch_size,) + shp, dtype=torch.float32, device=dev) for shp in MASK_SHAPES]
+    L.call("sp_training_masks", *[ops.ptr(t) for t in out], batch_size, ctypes.c_uint64(seed), float(p_random_mask), ops.stream())
     return out
 
 

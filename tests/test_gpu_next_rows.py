@@ -74,6 +74,23 @@ def test_device_mask_generation_contract_and_step():
         assert np.isfinite(float(out[n])), n
 
 
+@pytest.mark.parametrize("seed,p", [(0, 0.3), (12345678901234567, 0.3), (7, 1.0), (8, 0.0)])
+def test_device_mask_generator_is_bit_exact_with_the_oracle(seed, p):
+    """Row f1: sp_training_masks (one launch per batch, csrc/eltwise.hip) against oracle.training_masks - the generator is
+    integer arithmetic on a counter-based hash, so all seven tensors must be EQUAL, for every sample of a 384-sample batch
+    (every stage, spatial and non-spatial cases, 1-4 rectangles; p = 1 / p = 0 force both branches)."""
+    from oracle import sempyr_oracle as O
+    got = synthetic.training_masks_device(384, "cuda", seed=seed, p_random_mask=p)
+    want = O.training_masks(384, seed, p)
+    torch.cuda.synchronize()
+    assert [tuple(t.shape) for t in got] == [tuple(t.shape) for t in want]
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert torch.equal(g.cpu(), w), (seed, p, i, int((g.cpu() != w).sum()))
+    dec = O.training_mask_decisions(384, seed, p)
+    assert {s for s, _ in dec} == set(range(7))
+    assert any(sp for _, sp in dec) == (p > 0)
+
+
 def test_checkpoint_round_trip_on_the_device(tmp_path):
     """Row f3: iteration 1, checkpoint in the reference's layout, fresh objects restored from the file, iteration 2 - against the
     uninterrupted run.  fp32 mode reduces in a fixed order, so the two runs must agree bit for bit."""

@@ -68,3 +68,31 @@ def test_discriminator_output_shape_quirk():
     x = torch.randn(3, 3, 256, 256)
     labels = torch.nn.functional.one_hot(torch.tensor([1, 5, 9]), 365)
     assert O.discriminator_forward(D, x, labels).shape == (3, 3, 128)
+
+
+def test_mask_generator_statistics_match_the_reference_generator():
+    """Row f1: the device mask generator's decisions (restated bit for bit in oracle.training_mask_decisions; the GPU test
+    holds the kernel to the restatement) against the statistics of the UNMODIFIED reference generator
+    (tests/golden/mask_stats.json, recorded by tests/golden/make_mask_stats.py from /root/reference/misc.py:13-68 over 45 000
+    calls): the joint frequencies of (open stage, spatial mask used) must agree within 4.5 sigma of the two-sample binomial
+    spread in every one of the 12 cells the reference produces - and no other cell may occur."""
+    import json
+    import math
+    import os
+    from oracle import sempyr_oracle as O
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mask_stats.json")))
+    n_ref = ref["n"]
+    ref_counts = {(s, bool(sp)): c for s, sp, c in ref["counts"]}
+    n = 45000
+    counts = {}
+    for s, sp in O.training_mask_decisions(n, 20260, 0.3):
+        counts[(s, sp)] = counts.get((s, sp), 0) + 1
+    assert set(counts) == set(ref_counts), (sorted(counts), sorted(ref_counts))
+    for cell, c_ref in ref_counts.items():
+        p_ref, p_got = c_ref / n_ref, counts[cell] / n
+        pooled = (c_ref + counts[cell]) / (n_ref + n)
+        sigma = math.sqrt(pooled * (1 - pooled) * (1 / n_ref + 1 / n))
+        assert abs(p_got - p_ref) <= 4.5 * sigma, (cell, p_got, p_ref, sigma)
+    # the closed-form probabilities of misc.py:28-34: stage ~ choice([0..6, 0, 1]), spatial with p = 0.3 for 0 < stage < 6
+    spatial = sum(c for (s, sp), c in counts.items() if sp) / n
+    assert abs(spatial - 0.3 * 6 / 9) < 0.01
