@@ -492,6 +492,20 @@ def main():
                 line["bf16_parity"] = bf16_parity_record(dev)
             except Exception as exc:                             # a reported figure, not the thing measured: never sink the line
                 line["bf16_parity"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        if world == 1 and not args.no_sub_records and args.dtype == "bf16":
+            # BASELINE.json config 5 (one GPU's share): the same step with the VGG-16 pyramid's wide 3x3 layers on the fp8 MFMA
+            from semantic_pyramid_for_image_generation_amd import ops as _ops
+            _ops.set_vgg_fp8(1)
+            try:
+                line["fp8"] = sub_record(cf, args.batch, args.dtype, dev, 15, 5, not args.no_graphs)
+                line["fp8"]["note"] = ("config 5 slice (ops.set_vgg_fp8(1)): e4m3 operands on v_mfma_f32_16x16x32_fp8_fp8 for 8 of VGG-16's 13 "
+                                       "convolutions in the no-gradient pass (delayed per-tensor activation scales, per-channel filter scales), "
+                                       "bf16 elsewhere; parity restated in tests/test_gpu_fp8.py (taps <= 8.3e-2 rel-L2, golden-step losses 1.4e-2, "
+                                       "rec-loss gradient cosine 0.45 with fp32 vs 0.84 for bf16)")
+            except Exception as exc:
+                line["fp8"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            finally:
+                _ops.set_vgg_fp8(False)
         if world == 1 and not args.no_sub_records:
             # DVFS-steady throughput: the headline window (K steps) can be shorter than the clock governor's settling time
             n_sus = max(args.steps, int(6.0 / max(ms * 1e-3, 1e-4)))

@@ -33,7 +33,7 @@ extern "C" {
 typedef void* sp_stream_t;
 
 enum sp_status { SP_OK = 0, SP_ERR_INVALID = -1, SP_ERR_LAUNCH = -2, SP_ERR_UNSUPPORTED = -3 };
-enum sp_dtype { SP_F32 = 0, SP_BF16 = 1 };
+enum sp_dtype { SP_F32 = 0, SP_BF16 = 1, SP_F8 = 2 /* OCP e4m3 operands, see sp_conv_params: x_scale .. y8_amax */ };
 enum sp_act { SP_ACT_NONE = 0, SP_ACT_LRELU = 1, SP_ACT_RELU = 2, SP_ACT_TANH = 3 };
 
 int sp_version(void);
@@ -105,6 +105,19 @@ typedef struct sp_conv_params {
     int32_t in_up2;         /* 1: x is [n][h/2][w/2][cin_p] and the convolution runs over 1/4 x its nearest-neighbour x2 expansion,
                              * i.e. over the gradient of a 2x2 average pooling that is never written out (input-gradient pass of
                              * a pool2 layer).  3x3, cout > 32, h % 8 == 0, w % 32 == 0 (SP_ERR_INVALID otherwise) */
+    /* dtype == SP_F8 (BASELINE.json config 5: fp8 MFMA implicit-GEMM path; the frozen VGG-16 pyramid's 3x3 layers with
+     * cout > 64, w % 32 == 0, h % 8 == 0, models.py:183-216): x and w hold OCP e4m3 bytes (cin_p a multiple of 16), the MFMA
+     * is v_mfma_f32_16x16x32_fp8_fp8, accumulation fp32:
+     *   v = act( conv(x, w) * x_scale[0] * w_scale[co] + bias[co] ), optionally 2x2 max-pooled (pool2 = 2),
+     * stored as bf16 into y (may be NULL) and / or re-quantised, q = sat(v * y8_inv_scale[0]), as e4m3 into y8 (may be NULL;
+     * same [n][h][w][ldy] geometry) for the next layer of the chain; max|v| is merged into y8_amax[0] (atomic max on the fp32
+     * bit pattern, v >= 0 after ReLU) for the delayed scaling of the next call.  act NONE / ReLU, no residuals, no mask_src,
+     * no in_up2, pool2 0 / 2, cout % 16 == 0.  All scale pointers are DEVICE pointers (no host round trip). */
+    const float* x_scale;   /* [1]    dequantisation scale of x                      (SP_F8 only) */
+    const float* w_scale;   /* [cout] dequantisation scale per output channel        (SP_F8 only) */
+    void* y8;               /* e4m3 output or NULL                                   (SP_F8 only) */
+    const float* y8_inv_scale; /* [1] quantisation scale of y8 (1 / its dequantisation scale), required with y8 */
+    float* y8_amax;         /* [1] running max of v, or NULL                         (SP_F8 only) */
 } sp_conv_params;
 int sp_conv2d_igemm(const sp_conv_params* p, sp_stream_t stream);
 /* Bytes of fp32 scratch sp_conv2d_igemm wants in sp_conv_params.workspace to split the K loop of this shape over several
@@ -349,6 +362,17 @@ int sp_div_loss_fwd(const void* img, int64_t half_elems, const float* z, int64_t
                     float* out2, int32_t dtype, sp_stream_t stream);
 int sp_div_loss_bwd(const void* img, int64_t half_elems, const float* fwd_out2, const float* gout, void* dimg,
                     int32_t dtype, sp_stream_t stream);
+
+/* fp8 (OCP e4m3) helpers of the SP_F8 convolution path (BASELINE.json config 5).
+ * sp_quantize_fp8: q[i] = e4m3(sat(x[i] * inv_scale[0])) for a bf16 / fp32 tensor of `numel` elements (numel % 16 == 0);
+ *   amax (may be NULL): max|x| merged into amax[0].
+ * sp_pack_weight_fp8: conv weight [cout][cin][3][3] fp32 (OIHW, the frozen VGG-16 filters) -> e4m3 [cout][9][cin_p] in the
+ *   forward packing of sp_conv2d_igemm with ONE scale per output channel, w_scale[co] = max|w[co]| / 448 (pad channels zero).
+ * sp_fp8_update_scales: delayed scaling - for each of n slots: if amax[i] > 0: scale[i] = margin * amax[i] / 448,
+ *   inv_scale[i] = 1 / scale[i]; amax[i] = 0.  One launch, no host sync. */
+int sp_quantize_fp8(const void* x, void* q, int64_t numel, const float* inv_scale, float* amax, int32_t dtype, sp_stream_t stream);
+int sp_pack_weight_fp8(const float* w, int32_t cout, int32_t cin, int32_t cin_p, void* out, float* w_scale, sp_stream_t stream);
+int sp_fp8_update_scales(float* amax, float* scale, float* inv_scale, int32_t n, float margin, sp_stream_t stream);
 
 /* A batch of training masks generated on the device: misc.get_masks_for_training
  * (/root/reference/misc.py:13-68) for every sample of the batch in one launch - stage ~ choice([0..6, 0, 1]) counted from the deep

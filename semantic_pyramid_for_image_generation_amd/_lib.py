@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "sempyr.h")
 LIB_PATH = os.environ.get("SEMPYR_LIB") or os.path.join(_HERE, "libsempyr.so")     # SEMPYR_LIB: A/B runs of two builds
 
-SP_F32, SP_BF16 = 0, 1
+SP_F32, SP_BF16, SP_F8 = 0, 1, 2
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 
 # sp_set_tuning keys (include/sempyr.h).  The library reads no environment variables itself; an environment variable of
@@ -35,7 +35,9 @@ class SpConvParams(ctypes.Structure):
                 ("n", ctypes.c_int32), ("h", ctypes.c_int32), ("w_", ctypes.c_int32), ("cin_p", ctypes.c_int32),
                 ("cout", ctypes.c_int32), ("ldy", ctypes.c_int32), ("ksize", ctypes.c_int32), ("act", ctypes.c_int32),
                 ("dtype", ctypes.c_int32), ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64),
-                ("pool2", ctypes.c_int32), ("in_up2", ctypes.c_int32)]
+                ("pool2", ctypes.c_int32), ("in_up2", ctypes.c_int32),
+                ("x_scale", ctypes.c_void_p), ("w_scale", ctypes.c_void_p), ("y8", ctypes.c_void_p),
+                ("y8_inv_scale", ctypes.c_void_p), ("y8_amax", ctypes.c_void_p)]
 
 
 class SpSnLayer(ctypes.Structure):

@@ -6,7 +6,7 @@ OUT=../libsempyr.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result"
 mkdir -p build
 pids=()
-for f in conv_igemm conv_pp conv_wgrad conv_wgrad_rows conv_wgrad_1x1 spectral_norm linear eltwise norm resample attention losses optim; do
+for f in conv_igemm conv_pp fp8 conv_wgrad conv_wgrad_rows conv_wgrad_1x1 spectral_norm linear eltwise norm resample attention losses optim; do
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ conv_common.h -nt build/$f.o ] || [ ../../include/sempyr.h -nt build/$f.o ]; then
     hipcc $FLAGS -c $f.hip -o build/$f.o &
     pids+=($!)
@@ -14,6 +14,6 @@ for f in conv_igemm conv_pp conv_wgrad conv_wgrad_rows conv_wgrad_1x1 spectral_n
 done
 for p in "${pids[@]}"; do wait $p; done
 hipcc $FLAGS -c api.cpp -o build/api.o
-OBJS=""; for f in conv_igemm conv_pp conv_wgrad conv_wgrad_rows conv_wgrad_1x1 spectral_norm linear eltwise norm resample attention losses optim api; do OBJS="$OBJS build/$f.o"; done
+OBJS=""; for f in conv_igemm conv_pp fp8 conv_wgrad conv_wgrad_rows conv_wgrad_1x1 spectral_norm linear eltwise norm resample attention losses optim api; do OBJS="$OBJS build/$f.o"; done
 hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $OUT
 echo "built $(realpath $OUT)"

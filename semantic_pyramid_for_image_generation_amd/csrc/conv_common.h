@@ -23,6 +23,18 @@ template <> struct Mma<float> {
     }
 };
 
+struct f8 { uint8_t v; };                        // OCP e4m3 storage (SP_F8): 16 elements per 16-byte fragment read
+template <> struct Mma<f8> {
+    // a / b: 16 consecutive k of one row (bytes 0-7 feed the first MFMA, 8-15 the second; A and B use the same split, so the
+    // sum over the 64-byte chunk is complete)
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& c) {
+        const long a0 = (long)(((unsigned long long)a.y << 32) | a.x), a1 = (long)(((unsigned long long)a.w << 32) | a.z);
+        const long b0 = (long)(((unsigned long long)b.y << 32) | b.x), b1 = (long)(((unsigned long long)b.w << 32) | b.z);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a0, b0, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a1, b1, c, 0, 0, 0);
+    }
+};
+
 template <int... I, typename F>
 __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, typename F>

@@ -1581,10 +1581,20 @@ extern "C" int sp_conv2d_workspace(int32_t n, int32_t h, int32_t w_, int32_t cin
 extern "C" int sp_conv2d_igemm(const sp_conv_params* pp, sp_stream_t stream) {
     SP_CHECK_ARG(pp != nullptr, "sp_conv2d_igemm: null params");
     const sp_conv_params& p = *pp;
-    SP_CHECK_ARG(p.x && p.w && p.y, "sp_conv2d_igemm: null tensor pointer");
+    SP_CHECK_ARG(p.x && p.w && (p.y || (p.dtype == SP_F8 && p.y8)), "sp_conv2d_igemm: null tensor pointer");
     SP_CHECK_ARG(p.ksize == 1 || p.ksize == 3, "sp_conv2d_igemm: ksize %d unsupported (1 or 3)", p.ksize);
     SP_CHECK_ARG(p.n > 0 && p.h > 0 && p.w_ > 0 && p.cin_p > 0 && p.cout > 0, "sp_conv2d_igemm: bad dims");
-    SP_CHECK_ARG(p.dtype == SP_F32 || p.dtype == SP_BF16, "sp_conv2d_igemm: bad dtype %d", p.dtype);
+    SP_CHECK_ARG(p.dtype == SP_F32 || p.dtype == SP_BF16 || p.dtype == SP_F8, "sp_conv2d_igemm: bad dtype %d", p.dtype);
+    if (p.dtype == SP_F8) {
+        // BASELINE.json config 5: e4m3 operands on the fp8 MFMA, the ping-pong 3x3 kernel only (conv_pp.hip)
+        SP_CHECK_ARG(p.x_scale && p.w_scale && (!p.y8 || p.y8_inv_scale), "sp_conv2d_igemm: SP_F8 needs x_scale, w_scale (and y8_inv_scale with y8)");
+        SP_CHECK_ARG(p.cin_p % 16 == 0 && p.cout % 16 == 0 && p.ldy % 16 == 0 && p.ldy >= p.cout, "sp_conv2d_igemm: SP_F8 needs cin_p, cout, ldy multiples of 16");
+        SP_CHECK_ARG((p.act == SP_ACT_NONE || p.act == SP_ACT_RELU) && (p.pool2 == 0 || p.pool2 == 2) && !p.res1 && !p.res2 && !p.mask_src && !p.in_up2,
+                     "sp_conv2d_igemm: SP_F8 supports act NONE / ReLU, pool2 0 / 2, no residuals, no mask_src, no in_up2");
+        const int rc = sp_conv_pp_launch(p, 8, reinterpret_cast<hipStream_t>(stream));
+        if (rc == 1) { sp_set_error("sp_conv2d_igemm: SP_F8 covers 3x3 layers with cout > 64, h %% 8 == 0, w %% 32 == 0 only"); return SP_ERR_UNSUPPORTED; }
+        return rc;
+    }
     const int e = p.dtype == SP_F32 ? 4 : 8;
     SP_CHECK_ARG(p.cin_p % e == 0, "sp_conv2d_igemm: cin_p=%d must be a multiple of %d (16 bytes)", p.cin_p, e);
     SP_CHECK_ARG(p.ldy >= p.cout, "sp_conv2d_igemm: ldy < cout");

@@ -49,7 +49,9 @@ struct PPGeom {
     static constexpr int HPS0 = (HPW + 1) / 2, HPS1 = HPW - HPS0;     // issued in stage 0 / stage 1 of the previous chunk
     static constexpr int W_BYTES = 3 * CO_T * 64, W_PER = 3;          // one weight stage = 24 wave-instructions, 3 per wave
     static constexpr int NWS = 4;                                     // weight ring slots
-    static constexpr int OFF_W = 2 * HALO_BUF, OFF_BIAS = OFF_W + NWS * W_BYTES, OFF_DUMMY = OFF_BIAS + PP_BIAS_MAX * 4;
+    static constexpr bool F8 = sizeof(T) == 1;                        // SP_F8: e4m3 operands, per-channel dequantisation scales in LDS
+    static constexpr int OFF_W = 2 * HALO_BUF, OFF_BIAS = OFF_W + NWS * W_BYTES, OFF_SCALE = OFF_BIAS + PP_BIAS_MAX * 4;
+    static constexpr int OFF_DUMMY = OFF_SCALE + (F8 ? PP_BIAS_MAX * 4 : 0);
     static constexpr int LDS = OFF_DUMMY + 1024;
 };
 
@@ -92,6 +94,11 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
         float* bias_l = reinterpret_cast<float*>(smem + G::OFF_BIAS);
         const int nb = cotiles * CO_T < PP_BIAS_MAX ? cotiles * CO_T : PP_BIAS_MAX;
         for (int i = tid; i < nb; i += 512) bias_l[i] = (p.bias != nullptr && i < p.cout) ? p.bias[i] : 0.f;
+        if constexpr (G::F8) {                               // dequantisation scale of (x, w[co]) per output channel
+            float* scale_l = reinterpret_cast<float*>(smem + G::OFF_SCALE);
+            const float sx = p.x_scale[0];
+            for (int i = tid; i < nb; i += 512) scale_l[i] = i < p.cout ? sx * p.w_scale[i] : 0.f;
+        }
     }
 
     // ---- DMA descriptors (raw buffers: SGPR base + 32-bit byte offset per lane; an offset beyond num_records reads zeros)
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
         b_addr[ds] = lds_base + ((RW * wpx) * HP + frow + ds) * 64 + ((fslot ^ (((frow + ds) >> 1) & 3)) << 4);
     const unsigned bias_addr = lds_base + G::OFF_BIAS + (wco * 64 + (lane >> 4) * 16) * 4;
 
-    const bool bias_in_acc = p.bias != nullptr && !up && cotiles * CO_T <= PP_BIAS_MAX;
+    const bool bias_in_acc = !G::F8 && p.bias != nullptr && !up && cotiles * CO_T <= PP_BIAS_MAX;   // (SP_F8: the bias follows the scale)
     f32x4_t acc[4][NFR];
     auto init_acc = [&](bool live, int co0) {
         uint4 b4[4];
@@ -240,6 +247,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
         }
     };
     if constexpr (TIMING) tprev = __builtin_readcyclecounter();
+    float vmax = 0.f;                                       // SP_F8: running max of this lane's outputs (merged once per block at the end)
     int g4 = 0;                                             // weight ring slot of the stage being computed (stage index mod 4)
     int kc = 0;
     const bool vec_ok = ((p.ldy & 3) == 0) && ((p.cout & 3) == 0);
@@ -329,6 +337,74 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
 #pragma unroll
                     for (int j = 0; j < NFR; ++j) acc[i][j] *= 0.25f;
             }
+            if constexpr (G::F8) {
+                // SP_F8 epilogue: v = relu(acc * scale[co] + bias[co]) (the 2x2 maximum first: it commutes with the positive scale,
+                // the bias and the ReLU), stored as bf16 and / or re-quantised to e4m3 for the next layer; running max for its scale
+                uint4 sc4[4], bi4[4];
+                const unsigned sa = bias_addr + (unsigned)(G::OFF_SCALE - G::OFF_BIAS) + (unsigned)co0 * 4u, ba = bias_addr + (unsigned)co0 * 4u;
+                lds_rd128<0>(sc4[0], sa); lds_rd128<16>(sc4[1], sa); lds_rd128<32>(sc4[2], sa); lds_rd128<48>(sc4[3], sa);
+                lds_rd128<0>(bi4[0], ba); lds_rd128<16>(bi4[1], ba); lds_rd128<32>(bi4[2], ba); lds_rd128<48>(bi4[3], ba);
+                wait_lgkm<0>();
+                float sc[16], bi[16];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    sc[i * 4] = __uint_as_float(sc4[i].x); sc[i * 4 + 1] = __uint_as_float(sc4[i].y); sc[i * 4 + 2] = __uint_as_float(sc4[i].z); sc[i * 4 + 3] = __uint_as_float(sc4[i].w);
+                    bi[i * 4] = __uint_as_float(bi4[i].x); bi[i * 4 + 1] = __uint_as_float(bi4[i].y); bi[i * 4 + 2] = __uint_as_float(bi4[i].z); bi[i * 4 + 3] = __uint_as_float(bi4[i].w);
+                }
+                const float inv_sy = p.y8 != nullptr ? p.y8_inv_scale[0] : 0.f;
+                bf16* yb = reinterpret_cast<bf16*>(p.y);
+                uint8_t* y8 = reinterpret_cast<uint8_t*>(p.y8);
+                const bool relu = p.act == SP_ACT_RELU;
+                auto finish = [&](float (&v)[16], long opix) {          // one pixel x 16 channels of the (pooled) output
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        v[c] = v[c] * sc[c] + bi[c];
+                        if (relu) v[c] = fmaxf(v[c], 0.f);
+                        vmax = fmaxf(vmax, fabsf(v[c]));
+                    }
+                    const long off = opix * p.ldy + co_b;
+                    if (yb != nullptr) Wide16<bf16>::st(yb + off, v);
+                    if (y8 != nullptr) {
+                        unsigned w4[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            float q[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) q[e] = fminf(fmaxf(v[k * 4 + e] * inv_sy, -448.f), 448.f);
+                            int pk = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], 0, false);
+                            pk = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], pk, true);
+                            w4[k] = (unsigned)pk;
+                        }
+                        *reinterpret_cast<uint4*>(y8 + off) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                    }
+                };
+                static_for<NFR>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    if (p.pool2) {
+                        if constexpr ((j & 3) == 0) {
+                            const bool odd = lane & 1;
+                            float v[16];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const float a = fmaxf(acc[i][j][r], acc[i][j + 2][r]), b = fmaxf(acc[i][j + 1][r], acc[i][j + 3][r]);
+                                    const float recv = dpp_xor1(odd ? a : b);
+                                    v[i * 4 + r] = fmaxf(odd ? b : a, recv);
+                                }
+                            const long prow = ((long)n * (H >> 1) + ((ty0 + RW * wpx + (j >> 1)) >> 1)) * (W >> 1);
+                            finish(v, prow + (tx0 >> 1) + (odd ? 8 : 0) + ((lane & 15) >> 1));
+                        }
+                    } else {
+                        float v[16];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r];
+                        finish(v, pix0 + (long)(j >> 1) * W + (j & 1) * 16);
+                    }
+                });
+            } else
             static_for<NFR>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 const long pix = pix0 + (long)(j >> 1) * W + (j & 1) * 16;
@@ -374,6 +450,22 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
         }
     }
     if (!half_b) __builtin_amdgcn_s_barrier();              // the barrier the other half passes after its last MFMA segment
+    if constexpr (G::F8) {
+        // one atomic per BLOCK on the running maximum (per item and wave they serialise on one L2 word: 10 K atomics = 100+ us)
+        if (p.y8_amax != nullptr) {
+            float* red = reinterpret_cast<float*>(smem + G::OFF_DUMMY);
+            vmax = wave_max(vmax);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy kilobyte is the target of zero-fill requests: let them land
+            __builtin_amdgcn_s_barrier();
+            if (lane == 0) red[wave] = vmax;
+            __syncthreads();
+            if (tid == 0) {
+                float m = red[0];
+                for (int k = 1; k < 8; ++k) m = fmaxf(m, red[k]);
+                atomicMax(reinterpret_cast<unsigned*>(p.y8_amax), __float_as_uint(m));
+            }
+        }
+    }
     if constexpr (TIMING) {
         if (lane == 0 && p.workspace != nullptr) {
             float* out = reinterpret_cast<float*>(p.workspace) + ((long)blockIdx.x * 8 + wave) * 8;
@@ -408,6 +500,11 @@ int launch_pp(const sp_conv_params& p, int prio, hipStream_t s) {
 // conv_igemm.hip's dispatch(): bf16 3x3 layers with more than 64 output channels on (th x 32)-pixel patches, th = 8 or 16.
 // Returns 1 if the shape is not covered (the caller then keeps its own kernel).
 int sp_conv_pp_launch(const sp_conv_params& p, int th, hipStream_t s) {
+    if (p.dtype == SP_F8) {
+        if (p.ksize != 3 || p.cout <= 64 || p.h % 8 != 0 || p.w_ % PP_TW != 0 || (long)p.n * p.h * p.w_ * p.cin_p >= (1L << 30) ||
+            (long)p.cout * 9 * p.cin_p >= (1L << 30) || (p.cout + 127) / 128 * 128 > PP_BIAS_MAX) return 1;
+        return launch_pp<f8, 8, 1>(p, 1, s);
+    }
     if (p.dtype != SP_BF16 || p.ksize != 3 || p.cout <= 64 || p.h % th != 0 || p.w_ % PP_TW != 0) return 1;
     const long esz = 2;
     if ((long)p.n * p.h * p.w_ * p.cin_p * esz >= (1L << 30) || (long)p.cout * 9 * p.cin_p * esz >= (1L << 30)) return 1;

@@ -482,6 +482,23 @@ class _VGGPyramidFn(torch.autograd.Function):
         # convolution is never looked at again, so its ReLU + MaxPool ride in the convolution's epilogue (pool2 = 2)
         fuse_pool = _FUSE_POOL2 and not ctx.needs_input_grad[0]
         skip_pool = False
+        # BASELINE.json config 5 (ops.set_vgg_fp8): layers of the fp8 chain take e4m3 operands on the fp8 MFMA.  x8 = the e4m3 copy
+        # of x (slot = index of its scale), produced by the previous layer's epilogue or by sp_quantize_fp8 where the producer is
+        # a bf16 kernel; bf16 outputs are still written wherever the pyramid taps / the backward pass need them.
+        f8 = packs.get("f8")
+        if f8 is not None and ctx.needs_input_grad[0] and f8["mode"] < 2:
+            f8 = None                                        # mode 1: the pass with gradient stays bf16 (ops.set_vgg_fp8)
+        calibrating = f8 is not None and not f8["calibrated"]
+        x8 = None
+
+        def in_chain(conv_idx, hh, ww):                      # the fp8 kernel's shapes (include/sempyr.h, SP_F8)
+            return f8 is not None and conv_idx in f8["w"] and hh % 8 == 0 and ww % 32 == 0
+
+        def to_fp8(t, slot):
+            if calibrating:                                  # first call: bf16 pass; record max|x| of every chain input once
+                f8["amax"][slot:slot + 1].copy_(t.detach().float().abs().amax().reshape(1))
+                return None
+            return ops.quantize_fp8(t, f8["inv"][slot:slot + 1], f8["amax"][slot:slot + 1])
         for k, v in enumerate(_VGG_CFG):
             if v == "M" and skip_pool:
                 skip_pool = False
@@ -494,9 +511,44 @@ class _VGGPyramidFn(torch.autograd.Function):
                 trace.append(("pool", len(acts) - 1))
                 h, w = h // 2, w // 2
                 feats.append(y)
+                x8 = None                                                # pooled by the bf16 kernel: the next fp8 layer quantises it
+            elif in_chain(ci, h, w):
+                pk = packs["conv"][ci]
+                slot = ci                                                # one scale slot per convolution input
+                nxt_is_pool = k + 1 < len(_VGG_CFG) and _VGG_CFG[k + 1] == "M"
+                nh, nw = (h // 2, w // 2) if nxt_is_pool else (h, w)
+                nslot = ci + 1 if in_chain(ci + 1, nh, nw) else None    # an fp8 layer behind this one (possibly across the pool)?
+                if x8 is None:
+                    x8 = to_fp8(x, slot)
+                ci += 1
+                if calibrating:                                          # plain bf16 layer this once (the recorded maxima set the scales)
+                    y = ops.nhwc_empty(n, v, h, w, dtype, dev)
+                    ops.conv_launch(x, pk["fwd"].data_ptr(), pk["bias"], y, None, None, None, 0.0, n, h, w, x.shape[1], v, v, 3, ACT_RELU, dtype)
+                    x8 = None
+                    trace.append(("conv", len(acts) - 1, pk))
+                else:
+                    w8, w_scale, cin_p8 = f8["w"][ci - 1]
+                    pool_here = fuse_pool and nxt_is_pool
+                    oh, ow = (h // 2, w // 2) if pool_here else (h, w)
+                    want_next8 = nslot is not None and (pool_here or not nxt_is_pool)
+                    need_bf16 = ctx.needs_input_grad[0] or nxt_is_pool or nslot is None
+                    y = ops.nhwc_empty(n, v, oh, ow, dtype, dev) if need_bf16 else None
+                    y8 = torch.empty((n, oh, ow, v), dtype=torch.uint8, device=dev).permute(0, 3, 1, 2) if want_next8 else None
+                    ops.conv_launch_f8(x8, w8, w_scale, f8["scale"][slot:slot + 1], pk["bias"], y, y8,
+                                       f8["inv"][nslot:nslot + 1] if want_next8 else None, f8["amax"][nslot:nslot + 1] if want_next8 else None,
+                                       n, h, w, cin_p8, v, ACT_RELU, 2 if pool_here else 0)
+                    x8 = y8
+                    if pool_here:
+                        skip_pool = True
+                    trace.append(("conv", len(acts) - 1, pk))
+                    if y is None:                                        # only the e4m3 copy exists: nothing downstream reads bf16
+                        x = None
+                        acts.append(None)
+                        continue
             else:
                 pk = packs["conv"][ci]
                 ci += 1
+                x8 = None
                 if fuse_pool and k + 1 < len(_VGG_CFG) and _VGG_CFG[k + 1] == "M" and ops.conv_pool2_ok(h, w, v, 3):
                     y = ops.nhwc_empty(n, v, h // 2, w // 2, dtype, dev)
                     ops.conv_launch(x, pk["fwd"].data_ptr(), pk["bias"], y, None, None, None, 0.0, n, h, w, x.shape[1], v, v, 3, ACT_RELU,
@@ -523,6 +575,10 @@ class _VGGPyramidFn(torch.autograd.Function):
         h2 = lin(h1, fcs[1], 4096, ACT_RELU)
         logits = lin(h2, fcs[2], fcs[2]["n"], ACT_NONE)
         feats += [h2, logits]
+        if f8 is not None:                                   # delayed scaling: this pass's maxima set the next pass's scales
+            Lb.call("sp_fp8_update_scales", ops.ptr(f8["amax"]), ops.ptr(f8["scale"]), ops.ptr(f8["inv"]), f8["amax"].numel(),
+                    float(f8["margin"]), ops.stream())
+            f8["calibrated"] = True
         ctx.trace, ctx.packs, ctx.dtype, ctx.hw_last = trace, packs, dtype, (h, w)
         ctx.img_meta = (img.shape, img.dtype)
         ctx.save_for_backward(*acts, p7, h1, h2)
@@ -621,7 +677,7 @@ class VGG16(nn.Module):
 
     def _packed(self, dtype, device):
         params = list(self.vgg16.parameters())
-        key = (dtype, str(device)) + tuple((p.data_ptr(), p._version) for p in params)
+        key = (dtype, str(device), ops.vgg_fp8()) + tuple((p.data_ptr(), p._version) for p in params)
         if key == self._pack_key:
             return self._packs
         e = ops.chunk_elems(dtype)
@@ -649,6 +705,20 @@ class VGG16(nn.Module):
                 ops.L.call("sp_pack_weight", ops.ptr(w), o, k, k, 1, kp, np_, chw[0], chw[1], ops.ptr(fwd), ops.ptr(dg), sd, ops.stream())
                 packs["fc"].append({"fwd": fwd, "dgrad": dg, "kp": kp, "np": np_, "n": o,
                                     "bias": m.bias.detach().to(device=device, dtype=torch.float32).contiguous()})
+            if ops.vgg_fp8() > 0 and dtype == torch.bfloat16:
+                # BASELINE.json config 5: e4m3 filters (one scale per output channel) for every 3x3 layer the fp8 kernel can take
+                # (Cout > 64, Cin a multiple of 16); activation scales start uncalibrated (the first forward runs in bf16 and records them)
+                f8w, ci = {}, 0
+                for m in self.vgg16.features:
+                    if not isinstance(m, nn.Conv2d):
+                        continue
+                    if m.out_channels > 64 and m.in_channels % 16 == 0:
+                        f8w[ci] = ops.pack_weight_fp8(m.weight.detach().to(device=device, dtype=torch.float32))
+                    ci += 1
+                packs["f8"] = {"w": f8w, "scale": torch.ones(ci + 1, dtype=torch.float32, device=device),
+                               "inv": torch.ones(ci + 1, dtype=torch.float32, device=device),
+                               "amax": torch.zeros(ci + 1, dtype=torch.float32, device=device), "calibrated": False, "margin": 1.5,
+                               "mode": ops.vgg_fp8()}
         self._packs, self._pack_key = packs, key
         return packs
 
