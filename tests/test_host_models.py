@@ -82,12 +82,16 @@ def test_mask_generators_follow_the_contract():
 
 
 def test_device_mask_generator_follows_the_contract():
-    """Row f1: batched mask generation with tensor ops (runs on any device; here the CPU)."""
+    """Row f1: the device mask generator's contract, checked on the oracle's bit-exact restatement of the kernel
+    (oracle.training_masks; the GPU test holds sp_training_masks to it) - the product function itself has no CPU path."""
+    import pytest
     import torch.nn.functional as F
-    from semantic_pyramid_for_image_generation_amd import synthetic
+    from oracle import sempyr_oracle as O
+    from semantic_pyramid_for_image_generation_amd import _lib, synthetic
     shapes = [(1, 128, 128), (1, 64, 64), (1, 32, 32), (1, 16, 16), (1, 8, 8), (4096,), (365,)]
-    g = torch.Generator().manual_seed(0)
-    masks = synthetic.training_masks_device(512, "cpu", g)
+    with pytest.raises(_lib.SempyrError):
+        synthetic.training_masks_device(4, "cpu")
+    masks = O.training_masks(512, 0)
     assert [tuple(t.shape[1:]) for t in masks] == shapes and all(t.dtype == torch.float32 for t in masks)
     stage_hist = torch.zeros(7)
     n_spatial = 0
