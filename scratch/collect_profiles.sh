@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round-2 profile collection on the GPU box: kernel-trace stats of bench.py, FETCH_SIZE / WRITE_SIZE passes (separate runs, as
-# MI355X_MICROARCH.md prescribes), SQ counters of the dominant kernel on its typical launch.  Output: gpurun_out/prof_r2/
+# MI355X_MICROARCH.md prescribes), SQ counters of the dominant kernel on its typical launch.  Output: gpurun_out/prof_r3/
 set -x
-OUT=/root/repo/gpurun_out/prof_r2
+OUT=/root/repo/gpurun_out/prof_r3
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 /root/repo/bench.py --steps 8 --warmup 2 --no-graphs --no-sub-records --no-cpu-baseline > $OUT/trace_bench.json 2> $OUT/trace.err

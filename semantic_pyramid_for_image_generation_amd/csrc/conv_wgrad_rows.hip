@@ -354,6 +354,304 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_rows_kernel(WrArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Ping-pong form of the row walker (round 3; wide maps, W % 32 == 0).  Same tile (64 co x 64 ci x 9 taps per block, a wave =
+// 64 co x 16 ci), same LDS image and transposed fragment reads as conv_wgrad_rows_kernel<0>, but
+//   * ONE block of 8 waves per CU instead of two of 4: the two waves of a SIMD hold the SAME dW tile and take alternate image
+//     rows, one segment apart (MI355X_MICROARCH.md, "Two waves per SIMD"): while one multiplies its row (36 + 4 MFMAs on
+//     registers only), its partner reads the 26 fragments of the next row and issues its share of the LDS-DMA;
+//   * a block walks a CONTIGUOUS range of image rows (flattened over image, strip, y), so the two halo rows are re-fetched only
+//     where a column starts; every step - halo or row - loads exactly one X row (+ one dY row) into ring slot `step mod 8`,
+//     every loading wave issues three requests per step (dummies where it has none), so all waits are `vmcnt(3)`;
+//   * at the end the second half hands its accumulators to the first through LDS (the rings are dead by then) and ONE partial
+//     tile per block goes to the slab area: 256 slabs of 147 KB per layer instead of 512 (the merge was 16 % of the family's time).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int WP_NS = 8, WP_D = 4;                           // ring slots (X and dY), request distance in steps
+constexpr int WP_XBYTES = WP_NS * WR_XSLOT, WP_YBYTES = WP_NS * WR_YSLOT;
+constexpr int WP_DUMMY = WP_XBYTES + WP_YBYTES;
+constexpr int WP_LDS = WP_DUMMY + 1024;                      // 74 752 B; the hand-over of 72 accumulator registers needs 73 728
+
+__global__ __launch_bounds__(512) void conv_wgrad_pp_kernel(WrArgs a, int rows_per_block, int rows_total) {
+    extern __shared__ __attribute__((aligned(16))) char wp_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave >> 2, wq = wave & 3;
+    const int H = a.H, W = a.W, CIN = a.CIN;
+    const int co0 = (blockIdx.y / a.ci_tiles) * 64, ci0 = (blockIdx.y % a.ci_tiles) * 64;
+    const int strips = W / 32;
+    const int R0 = (int)blockIdx.x * rows_per_block;
+    const int R1 = R0 + rows_per_block < rows_total ? R0 + rows_per_block : rows_total;
+    if (R0 >= R1) return;
+    const int segs = (R1 - 1) / H - R0 / H + 1;            // columns touched: each starts with two halo steps
+    const int S = (R1 - R0) + 2 * segs;
+    const int S_pad = S + (S & 1);
+    const unsigned lds_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)wp_smem);
+    constexpr unsigned OOB = 0x80000000u;
+    auto uniform_ptr = [](const void* q) {
+        const unsigned long long v = (unsigned long long)(uintptr_t)q;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return (void*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+    };
+    const int up = a.dy_up2 ? 1 : 0;
+    const int HY = H >> up, WY = W >> up;
+    const float oscale = up ? 0.25f : 1.f;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.x), 0, __builtin_amdgcn_readfirstlane(a.N * H * W * CIN * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.dy), 0, __builtin_amdgcn_readfirstlane(a.N * HY * WY * a.LD_DY * 2), 0x00020000);
+
+    // ---- DMA lanes: pixel (lane >> 3) of an 8-pixel piece, logical 16-byte slot swizzled by (pixel >> 1) & 3 (see the kernel above)
+    const int dpx = lane >> 3;
+    const int dls = ((((lane & 7) >> 1) ^ ((dpx >> 1) & 3)) << 1) | (lane & 1);
+    const bool x_ch_ok = ci0 + dls * 8 < CIN;
+    const bool y_ch_ok = co0 + dls * 8 < a.LD_DY;
+    const unsigned x_lane = (unsigned)((ci0 + dls * 8) * 2), y_lane = (unsigned)((co0 + dls * 8) * 2);
+
+    // step cursor: (image n, strip origin x0, row y) of the step being REQUESTED; phase 0 / 1: halo steps (X rows y-1, y), phase 2: row
+    // step (X row y + 1, dY row y, the MFMAs of row y).  All incremental - an integer division costs ~50 scalar instructions, and
+    // a LOAD segment that spends them is longer than the partner's MFMA segment: the byte offsets of the column advance by one
+    // row pitch per row and are rebuilt only where a column starts.
+    struct Cursor { int n, x0, y, phase; unsigned xoff, yoff; };     // xoff: pixel (n, y, x0 - 1) of x; yoff: column origin of dy
+    const unsigned x_pitch = (unsigned)(W * CIN * 2), y_pitch = (unsigned)(WY * a.LD_DY * 2);
+    auto rebase = [&](Cursor& c) {
+        c.xoff = (unsigned)(((c.n * H + c.y) * W + c.x0 - 1) * CIN * 2);
+        c.yoff = (unsigned)(((c.n * HY) * WY + (c.x0 >> up)) * a.LD_DY * 2);
+    };
+    auto advance = [&](Cursor& c) {
+        if (c.phase < 2) { ++c.phase; return; }
+        c.xoff += x_pitch;
+        if (++c.y == H) {
+            c.y = 0; c.phase = 0;
+            c.x0 += 32;
+            if (c.x0 == W) { c.x0 = 0; ++c.n; }
+            rebase(c);
+        }
+    };
+    // per-lane constants of this wave's pieces: X piece wq (and piece 4 for wave 0), dY piece wq
+    const int px_a = wq * 8 + dpx, px_b = 32 + dpx;
+    const unsigned xl_a = (unsigned)(px_a * CIN * 2) + x_lane, xl_b = (unsigned)(px_b * CIN * 2) + x_lane;
+    const unsigned yl = (unsigned)((((wq * 8 + dpx) >> up) * a.LD_DY) * 2) + y_lane;
+    // the requests of step `c` (index s), issued by the four waves of the half that owns step s - D: X pieces 0..4 of one row
+    // (wave wq takes piece wq, wave 0 also piece 4), dY pieces 0..3 (wave wq takes piece wq); everything else is a dummy
+    auto issue_step = [&](const Cursor& c, int s) {
+        const bool live = s < S;
+        const int yx = c.y + c.phase - 1;
+        const bool xrow_ok = live && (unsigned)yx < (unsigned)H;
+        const unsigned xbase = c.xoff + (unsigned)(c.phase - 1) * x_pitch;
+        const unsigned slot_x = (unsigned)((s & (WP_NS - 1)) * WR_XSLOT), slot_y = (unsigned)(WP_XBYTES + (s & (WP_NS - 1)) * WR_YSLOT);
+        const bool left_edge = c.x0 == 0, right_edge = c.x0 + 32 == W;
+        {
+            const bool ok = xrow_ok && x_ch_ok && !(left_edge && px_a == 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (__attribute__((address_space(3))) void*)(wp_smem + slot_x + (unsigned)wq * 1024u),
+                                                     16, (int)(ok ? xbase + xl_a : OOB), 0, 0, 0);
+        }
+        {
+            const bool real = wq == 0;
+            const bool ok = real && xrow_ok && x_ch_ok && px_b < 34 && !(right_edge && px_b == 33);
+            const unsigned m = real ? 0xffffffffu : 0u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (__attribute__((address_space(3))) void*)(wp_smem + (((slot_x + 4096u) & m) | ((unsigned)WP_DUMMY & ~m))),
+                                                     16, (int)(ok ? xbase + xl_b : OOB), 0, 0, 0);
+        }
+        {
+            const bool real = live && c.phase == 2;
+            const unsigned off = (real && y_ch_ok) ? c.yoff + (unsigned)(c.y >> up) * y_pitch + yl : OOB;
+            const unsigned m = real ? 0xffffffffu : 0u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(y_rsrc, (__attribute__((address_space(3))) void*)(wp_smem + (((slot_y + (unsigned)wq * 1024u) & m) | ((unsigned)WP_DUMMY & ~m))),
+                                                     16, (int)off, 0, 0, 0);
+        }
+    };
+
+    // ---- fragment read offsets (the row walker's)
+    const int i16 = lane & 15, g = lane >> 4;
+    const int prow = g * 4 + (i16 >> 2);
+    unsigned a_off[4], b_off[3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_off[i] = (unsigned)(prow * 128 + ((i ^ ((prow >> 1) & 3)) << 5) + (i16 & 3) * 8);
+#pragma unroll
+    for (int ds = 0; ds < 3; ++ds) b_off[ds] = (unsigned)((prow + ds) * 128 + ((wq ^ (((prow + ds) >> 1) & 3)) << 5) + (i16 & 3) * 8);
+
+    f32x4_t acc[9][4], accb[4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[t][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accb[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = a.dbias != nullptr && ci0 == 0 && wq == 0;
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
+
+    // ---- prologue: steps 0 .. D-1 (each half requests the steps of its parity), everything landed before the first read.  Only
+    // the REQUEST cursor exists; whether the step being computed is a row step comes out of a two-entry history of its phases
+    Cursor rq;
+    {
+        const int col = R0 / H;
+        rq.y = R0 - col * H; rq.n = col / strips; rq.x0 = (col - rq.n * strips) * 32; rq.phase = 0;
+        rebase(rq);
+    }
+    if (half) advance(rq);
+    int ph_now = rq.phase;                                  // phase of the step this half computes next ...
+    issue_step(rq, half);
+    advance(rq); advance(rq);
+    int ph_next = rq.phase;                                 // ... and of the one after (requested 2 iterations = D steps ahead)
+    issue_step(rq, half + 2);
+    advance(rq); advance(rq);
+    wr_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (half) __builtin_amdgcn_s_barrier();                 // this half runs one segment behind
+
+    for (int s = half; s < S_pad; s += 2) {
+        const bool compute = s < S && ph_now == 2;
+        ph_now = ph_next;
+        ph_next = rq.phase;                                 // the step requested in this iteration: s + D
+        // ================= LOAD segment =================
+        uint2 alo[4], ahi[4], blo[9], bhi[9];
+        const unsigned ab = lds_base + (unsigned)(WP_XBYTES + (s & (WP_NS - 1)) * WR_YSLOT);
+        unsigned bb[3];
+#pragma unroll
+        for (int dr = 0; dr < 3; ++dr) bb[dr] = lds_base + (unsigned)(((s - 2 + dr) & (WP_NS - 1)) * WR_XSLOT);
+        if (compute) {
+            // fragment halves pinned to adjacent registers v180 .. v231 (A: 180-195, B: 196-231): with free allocation hipcc builds every
+            // MFMA operand tuple with two v_mov_b64 (80 moves per 40 MFMAs inside the MFMA segment)
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:0" : "={v[180:181]}"(alo[0]) : "v"(ab + a_off[0]));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "={v[182:183]}"(ahi[0]) : "v"(ab + a_off[0]));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:0" : "={v[184:185]}"(alo[1]) : "v"(ab + a_off[1]));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "={v[186:187]}"(ahi[1]) : "v"(ab + a_off[1]));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:0" : "={v[188:189]}"(alo[2]) : "v"(ab + a_off[2]));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "={v[190:191]}"(ahi[2]) : "v"(ab + a_off[2]));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:0" : "={v[192:193]}"(alo[3]) : "v"(ab + a_off[3]));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "={v[194:195]}"(ahi[3]) : "v"(ab + a_off[3]));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:0" : "={v[196:197]}"(blo[0]) : "v"(bb[0] + b_off[0]));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "={v[198:199]}"(bhi[0]) : "v"(bb[0] + b_off[0]));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:0" : "={v[200:201]}"(blo[1]) : "v"(bb[0] + b_off[1]));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "={v[202:203]}"(bhi[1]) : "v"(bb[0] + b_off[1]));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:0" : "={v[204:205]}"(blo[2]) : "v"(bb[0] + b_off[2]));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "={v[206:207]}"(bhi[2]) : "v"(bb[0] + b_off[2]));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:0" : "={v[208:209]}"(blo[3]) : "v"(bb[1] + b_off[0]));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "={v[210:211]}"(bhi[3]) : "v"(bb[1] + b_off[0]));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:0" : "={v[212:213]}"(blo[4]) : "v"(bb[1] + b_off[1]));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "={v[214:215]}"(bhi[4]) : "v"(bb[1] + b_off[1]));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:0" : "={v[216:217]}"(blo[5]) : "v"(bb[1] + b_off[2]));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "={v[218:219]}"(bhi[5]) : "v"(bb[1] + b_off[2]));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:0" : "={v[220:221]}"(blo[6]) : "v"(bb[2] + b_off[0]));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "={v[222:223]}"(bhi[6]) : "v"(bb[2] + b_off[0]));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:0" : "={v[224:225]}"(blo[7]) : "v"(bb[2] + b_off[1]));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "={v[226:227]}"(bhi[7]) : "v"(bb[2] + b_off[1]));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:0" : "={v[228:229]}"(blo[8]) : "v"(bb[2] + b_off[2]));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "={v[230:231]}"(bhi[8]) : "v"(bb[2] + b_off[2]));
+        }
+        issue_step(rq, s + WP_D);
+        advance(rq); advance(rq);
+        wr_wait_vmcnt<3>();                                 // everything this wave requested before this segment has landed
+        wr_wait_lgkm<0>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ================= MFMA segment =================
+        if (compute) {
+            __builtin_amdgcn_s_setprio(1);
+            wr_static_for<9>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                const bf16x8_t bf = wr_frag(blo[t], bhi[t]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr_frag(alo[i], ahi[i]), bf, acc[t][i], 0, 0, 0);
+            });
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr_frag(alo[i], ahi[i]), ones, accb[i], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!half) __builtin_amdgcn_s_barrier();               // the barrier the other half passes after its last segment
+
+    // ---- the second half's accumulators join the first half's through LDS (two passes of 72 registers + the bias sums)
+    wr_wait_vmcnt<0>();                                     // no request may land in the area any more
+    __syncthreads();
+    float* xch = reinterpret_cast<float*>(wp_smem);
+    const int ltid = tid & 255;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (half) {
+            int k = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (((t * 4 + i) & 1) == pass) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) xch[(k * 4 + r) * 256 + ltid] = acc[t][i][r];
+                        ++k;
+                    }
+                }
+        }
+        __syncthreads();
+        if (!half) {
+            int k = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (((t * 4 + i) & 1) == pass) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[t][i][r] += xch[(k * 4 + r) * 256 + ltid];
+                        ++k;
+                    }
+                }
+        }
+        __syncthreads();
+    }
+    if (a.dbias != nullptr && ci0 == 0) {                   // ... and the bias sums (block-uniform condition)
+        if (half) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xch[(i * 4 + r) * 256 + ltid] = accb[i][r];
+        }
+        __syncthreads();
+        if (!half) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) accb[i][r] += xch[(i * 4 + r) * 256 + ltid];
+        }
+    }
+    if (half) return;
+    // ---- merge of the block's tile: lane (ci = ci0 + wq*16 + i16, co = co0 + i*16 + g*4 + r), as the row walker
+    if (a.slabs != nullptr) {
+        float* slab = a.slabs + ((long)blockIdx.y * gridDim.x + blockIdx.x) * (9 * 64 * 64) + wq * 16 + i16;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slab[(t * 64 + i * 16 + g * 4 + r) * 64] = acc[t][i][r] * oscale;
+    }
+    const int ci = ci0 + wq * 16 + i16;
+    if (a.slabs == nullptr && ci < CIN) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + i * 16 + g * 4 + r;
+                    if (co < a.COUT) atomicAdd(a.dw + ((long)co * 9 + t) * CIN + ci, acc[t][i][r] * oscale);
+                }
+    }
+    if (do_bias && i16 == 0) {
+        float* bp = a.bias_part != nullptr ? a.bias_part + ((long)(blockIdx.y / a.ci_tiles) * gridDim.x + blockIdx.x) * 64 : nullptr;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = i * 16 + g * 4 + r;
+                if (bp != nullptr) bp[col] = accb[i][r] * oscale;
+                else if (co0 + col < a.COUT) atomicAdd(a.dbias + co0 + col, accb[i][r] * oscale);
+            }
+    }
+}
+
 // dW[co][tap][ci] += sum over the nblk slabs of pair blockIdx.y; blockIdx.z takes every gridDim.z-th slab (a pair with
 // hundreds of slabs would otherwise be summed by 36 blocks in one long dependent chain) and the few partial sums meet in
 // dW through atomics.
@@ -466,6 +764,33 @@ int sp_wgrad_rows_launch(const void* x, const void* dy, float* dw, float* dbias,
     }
     a.rows_per_unit = ru;
     a.units = groups * strips * (h / ru);
+    // wide maps: the ping-pong form (one 8-wave block per CU, contiguous row ranges, half the partial tiles)
+    if (nw == 0 && sp_tune(SP_TUNE_WGRAD_PP, 1)) {
+        const int rows_total = n * strips * h;
+        int nb = 256 / pairs;                                // one block per CU over all (co, ci) pairs of the layer
+        if (nb < 1) nb = 1;
+        int rpb = (rows_total + nb - 1) / nb;
+        if (rpb < 8) rpb = rows_total < 8 ? rows_total : 8;
+        nb = (rows_total + rpb - 1) / rpb;
+        static bool pp_attr = false;
+        if (!pp_attr) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WP_LDS);
+            if (e != hipSuccess) { sp_set_error("hipFuncSetAttribute(LDS=%d) failed: %s", WP_LDS, hipGetErrorString(e)); return SP_ERR_LAUNCH; }
+            pp_attr = true;
+        }
+        a.slabs = use_slabs && (long)nb * pairs <= 512 ? ws : nullptr;
+        a.bias_part = (a.slabs != nullptr && dbias != nullptr) ? ws + 512L * 9 * 64 * 64 : nullptr;
+        a.thin_mode = 0;
+        hipLaunchKernelGGL(conv_wgrad_pp_kernel, dim3((unsigned)nb, (unsigned)pairs), dim3(512), WP_LDS, s, a, rpb, rows_total);
+        if (a.slabs != nullptr) {
+            int z = 512 / (36 * pairs);
+            if (z > nb / 4) z = nb / 4;
+            if (z < 1 || det) z = 1;
+            hipLaunchKernelGGL(conv_wgrad_rows_reduce_kernel, dim3(9 * 64 * 16 / 256, (unsigned)pairs, (unsigned)z), dim3(256), 0, s, ws, nb, dw, cin, cout, a.ci_tiles, a.bias_part, dbias, det ? 1 : 0);
+        }
+        SP_LAUNCH_CHECK();
+        return SP_OK;
+    }
     // the slab area holds 512 partial tiles; the deterministic mode must not fall back to atomics with several blocks per pair
     if (det && (long)nblk * pairs > 512) nblk = 512 / pairs > 0 ? 512 / pairs : 1;
     static bool attr_set = false;
