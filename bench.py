@@ -181,7 +181,7 @@ def recorded_traffic(symbols):
             for kname, rec in kernels.items():
                 if symbol in kname:
                     return rec["hbm_bytes_per_launch"], {"file": "profiles/" + name, "sha256_16": hashlib.sha256(raw).hexdigest()[:16],
-                                                         "kernel": kname[:96], "launches_profiled": rec.get("launches")}
+                                                         "kernel": kname[:96], "launches_profiled": rec.get("launches_profiled")}
     return None, None
 
 

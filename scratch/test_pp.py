@@ -68,6 +68,11 @@ if __name__ == "__main__":
         dict(n=4, cin=256, cout=128, hw=64, up=True, act=0, bias=False, mask=True), dict(n=20, cin=256, cout=128, hw=128, up=True, act=0, bias=False),
         dict(n=20, cin=256, cout=512, hw=32, res=1, act=1), dict(n=20, cin=512, cout=256, hw=32), dict(n=1, cin=32, cout=128, hw=32),
         dict(n=13, cin=96, cout=130, hw=32),
+        # Cout <= 64: the 8-row-pair-wave form (WCO = 1, 16 x 32 patches)
+        dict(n=2, cin=64, cout=64, hw=64), dict(n=20, cin=64, cout=64, hw=256), dict(n=3, cin=128, cout=64, hw=128, res=2, act=0),
+        dict(n=2, cin=72, cout=64, hw=32, mask=True, act=0, bias=False), dict(n=2, cin=64, cout=64, hw=64, pool2=2, act=2),
+        dict(n=2, cin=64, cout=64, hw=64, pool2=1, res=1, act=0), dict(n=2, cin=128, cout=64, hw=64, up=True, act=0, bias=False),
+        dict(n=3, cin=32, cout=40, hw=32), dict(n=1, cin=64, cout=24, hw=32, act=3),
     ]
     for c in cases:
         ok = check(modes=modes, **c)
@@ -76,7 +81,7 @@ if __name__ == "__main__":
     print("ALL OK" if allok else "SOME FAILED", flush=True)
     # ---- timing: interleaved rounds, old vs pp modes
     B = 20
-    SHAPES = [(128, 128, 128), (256, 256, 64), (512, 512, 32), (64, 128, 128), (128, 256, 64), (256, 512, 32), (256, 256, 32), (264, 256, 32), (136, 128, 64)]
+    SHAPES = [(64, 64, 256), (128, 64, 128), (72, 64, 128), (128, 128, 128), (256, 256, 64), (512, 512, 32), (64, 128, 128), (128, 256, 64), (256, 512, 32), (256, 256, 32), (264, 256, 32), (136, 128, 64)]
     variants = [("old", 0, -1)] + [("pp%d/p%d" % (m, pr), m, pr) for m in modes for pr in (1, 9)]
     tot = {v[0]: 0.0 for v in variants}
     for cin, cout, hw in SHAPES:

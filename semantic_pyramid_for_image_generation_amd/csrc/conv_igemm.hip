@@ -1511,6 +1511,11 @@ int dispatch(const sp_conv_params& p, hipStream_t s) {
         const bool fits30 = (long)p.n * p.h * p.w_ * p.cin_p * esz < (1L << 30) && (long)p.cout * 9 * p.cin_p * esz < (1L << 30);
         const bool tall_ok = tall_mode && fits30 && p.h % TL_TH == 0 && p.w_ % TL_TW == 0;
         if (p.cout <= 64) {
+            // bf16, 16 < Cout <= 64 on 16-row patches: the ping-pong schedule with 8 row-pair waves (conv_pp.hip, WCO = 1)
+            if (tall_ok && sizeof(T) == 2 && p.cout > 16 && tall_mode <= 1 && sp_tune(SP_TUNE_CONV_PP, 1) && !(sp_tune(SP_TUNE_CONV_PP, 1) & 32)) {
+                const int rc = sp_conv_pp_launch(p, 16, s);
+                if (rc != 1) return rc;
+            }
             if (tall_ok) return launch_tall<T, 1>(p, s);
             return launch_halo<T, 64, 1>(p, s);
         }

@@ -38,16 +38,18 @@ constexpr int PP_TW = 32;
 constexpr int PP_NUM_CU = 256;                 // MI355X
 constexpr int PP_BIAS_MAX = 1024;              // output channels whose bias fits the LDS copy
 
-template <typename T, int TH>
+template <typename T, int WCO>
 struct PPGeom {
     static constexpr int E = 16 / (int)sizeof(T), KC = 4 * E;
-    static constexpr int CO_T = 128, WPX = 4, RW = TH / WPX, NB = RW + 2, NFR = RW * 2, HR = TH + 2;
-    static constexpr int HP = TH == 8 ? 40 : 36;                     // halo pitch in pixels (36: swizzle key bit 1 flips on odd rows)
+    // WCO = 2: 128 co x (8 x 32) px per block, waves = 2 (co halves) x 4 (row pairs);  WCO = 1 (Cout <= 64): 64 co x (16 x 32) px,
+    // waves = 8 row pairs.  Either way a wave owns 64 co x (2 rows x 32 columns): the same fragment / MFMA program.
+    static constexpr int CO_T = 64 * WCO, WPX = 8 / WCO, RW = 2, TH = WPX * RW, NB = RW + 2, NFR = RW * 2, HR = TH + 2;
+    static constexpr int HP = 40;                                     // halo pitch in pixels
     static constexpr int HALO_INSTR = (HR * HP * 64 + 1023) / 1024;   // wave-instructions of 1 KB per halo chunk
     static constexpr int HALO_BUF = HALO_INSTR * 1024;
     static constexpr int HPW = (HALO_INSTR + 7) / 8;                  // ... per wave (round robin; the tail ones are dummies)
     static constexpr int HPS0 = (HPW + 1) / 2, HPS1 = HPW - HPS0;     // issued in stage 0 / stage 1 of the previous chunk
-    static constexpr int W_BYTES = 3 * CO_T * 64, W_PER = 3;          // one weight stage = 24 wave-instructions, 3 per wave
+    static constexpr int W_BYTES = 3 * CO_T * 64, W_INSTR = W_BYTES / 1024, W_PER = (W_INSTR + 7) / 8;   // one weight stage: 24 / 12 wave-instructions, 3 / 2 per wave
     static constexpr int NWS = 4;                                     // weight ring slots
     static constexpr bool F8 = sizeof(T) == 1;                        // SP_F8: e4m3 operands, per-channel dequantisation scales in LDS
     static constexpr int OFF_W = 2 * HALO_BUF, OFF_BIAS = OFF_W + NWS * W_BYTES, OFF_SCALE = OFF_BIAS + PP_BIAS_MAX * 4;
@@ -66,11 +68,11 @@ constexpr int pp_group_index(int h, int dr, int rw) {
     return k;
 }
 
-template <typename T, int TH, int PRIO, bool TIMING = false, bool DMA_IN_L = true>
+template <typename T, int WCO, int PRIO, bool TIMING = false, bool DMA_IN_L = true>
 __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int cotiles, int total, int prio) {
-    using G = PPGeom<T, TH>;
-    constexpr int E = G::E, KC = G::KC, CO_T = G::CO_T, WPX = G::WPX, RW = G::RW, NB = G::NB, NFR = G::NFR, HR = G::HR, HP = G::HP;
-    constexpr int HALO_INSTR = G::HALO_INSTR, HALO_BUF = G::HALO_BUF, HPW = G::HPW, W_BYTES = G::W_BYTES, W_PER = G::W_PER;
+    using G = PPGeom<T, WCO>;
+    constexpr int E = G::E, KC = G::KC, CO_T = G::CO_T, WPX = G::WPX, RW = G::RW, NB = G::NB, NFR = G::NFR, HR = G::HR, HP = G::HP, TH = G::TH;
+    constexpr int HALO_INSTR = G::HALO_INSTR, HALO_BUF = G::HALO_BUF, HPW = G::HPW, W_BYTES = G::W_BYTES, W_PER = G::W_PER, W_INSTR = G::W_INSTR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
         for (int i = 0; i < W_PER; ++i) {
             const int row = (wave * W_PER + i) * 16 + l4;
             const int ts = row / CO_T, co = co0 + row % CO_T;          // tap row inside the stage; the stage adds the tap column
-            w_off[i] = co < p.cout ? (unsigned)(((co * 9 + ts * 3) * CIN + w_ls(i)) * (int)sizeof(T)) : OOB;
+            w_off[i] = (wave * W_PER + i < W_INSTR && co < p.cout) ? (unsigned)(((co * 9 + ts * 3) * CIN + w_ls(i)) * (int)sizeof(T)) : OOB;
         }
     };
     auto dma = [&](__amdgpu_buffer_rsrc_t rsrc, unsigned dst /* wave-uniform LDS byte offset */, unsigned voff) {
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
     auto issue_w_piece = [&](int i, bool valid, int c0, int ds, int slot) {
         const unsigned base = (unsigned)((ds * CIN + c0) * (int)sizeof(T));
         const unsigned add = c0 + w_ls(i) < CIN ? base : OOB_C;
-        const unsigned m = valid ? 0xffffffffu : 0u;
+        const unsigned m = (valid && wave * W_PER + i < W_INSTR) ? 0xffffffffu : 0u;   // (WCO = 1: 12 pieces on 16 slots)
         dma(w_rsrc, ((unsigned)(G::OFF_W + slot * W_BYTES + (wave * W_PER + i) * 1024) & m) | ((unsigned)G::OFF_DUMMY & ~m),
             ((w_off[i] + add) & m) | (OOB & ~m));
     };
@@ -475,18 +477,19 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
     }
 }
 
-template <typename T, int TH, int PRIO, bool TIMING = false, bool DMA_IN_L = true>
+template <typename T, int WCO, int PRIO, bool TIMING = false, bool DMA_IN_L = true>
 int launch_pp(const sp_conv_params& p, int prio, hipStream_t s) {
-    using G = PPGeom<T, TH>;
+    using G = PPGeom<T, WCO>;
+    constexpr int TH = G::TH;
     static_assert(G::LDS <= 163840, "LDS budget");
     static bool attr_set = false;
-    auto kern = conv3x3_pp_kernel<T, TH, PRIO, TIMING, DMA_IN_L>;
+    auto kern = conv3x3_pp_kernel<T, WCO, PRIO, TIMING, DMA_IN_L>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
         if (e != hipSuccess) { sp_set_error("hipFuncSetAttribute(LDS=%d) failed: %s", G::LDS, hipGetErrorString(e)); return SP_ERR_LAUNCH; }
         attr_set = true;
     }
-    const int cotiles = (p.cout + 127) / 128;
+    const int cotiles = (p.cout + G::CO_T - 1) / G::CO_T;
     const int total = p.n * (p.h / TH) * (p.w_ / PP_TW) * cotiles;
     int grid = total < PP_NUM_CU ? total : PP_NUM_CU;       // persistent: one block per CU
     if (grid >= 8) grid -= grid % 8;
@@ -503,14 +506,15 @@ int sp_conv_pp_launch(const sp_conv_params& p, int th, hipStream_t s) {
     if (p.dtype == SP_F8) {
         if (p.ksize != 3 || p.cout <= 64 || p.h % 8 != 0 || p.w_ % PP_TW != 0 || (long)p.n * p.h * p.w_ * p.cin_p >= (1L << 30) ||
             (long)p.cout * 9 * p.cin_p >= (1L << 30) || (p.cout + 127) / 128 * 128 > PP_BIAS_MAX) return 1;
-        return launch_pp<f8, 8, 1>(p, 1, s);
+        return launch_pp<f8, 2, 1>(p, 1, s);
     }
-    if (p.dtype != SP_BF16 || p.ksize != 3 || p.cout <= 64 || p.h % th != 0 || p.w_ % PP_TW != 0) return 1;
+    if (p.dtype != SP_BF16 || p.ksize != 3 || p.h % th != 0 || p.w_ % PP_TW != 0) return 1;
     const long esz = 2;
     if ((long)p.n * p.h * p.w_ * p.cin_p * esz >= (1L << 30) || (long)p.cout * 9 * p.cin_p * esz >= (1L << 30)) return 1;
     const int prio = sp_tune(SP_TUNE_CONV_PP_PRIO, 1);
-    if (th == 8 && (prio & 4)) return (prio & 8) ? launch_pp<bf16, 8, 1, true, false>(p, prio, s) : launch_pp<bf16, 8, 1, true, true>(p, prio, s);
-    if (th == 8 && (prio & 8)) return launch_pp<bf16, 8, 1, false, false>(p, prio, s);
-    if (th == 8) return (prio & 1) ? launch_pp<bf16, 8, 1>(p, prio, s) : launch_pp<bf16, 8, 0>(p, prio, s);
-    return 1;
+    if (th == 16 && p.cout <= 64) return (prio & 1) ? launch_pp<bf16, 1, 1>(p, prio, s) : launch_pp<bf16, 1, 0>(p, prio, s);   // 64 co x 16x32 px
+    if (th != 8 || p.cout <= 64) return 1;
+    if (prio & 4) return (prio & 8) ? launch_pp<bf16, 2, 1, true, false>(p, prio, s) : launch_pp<bf16, 2, 1, true, true>(p, prio, s);
+    if (prio & 8) return launch_pp<bf16, 2, 1, false, false>(p, prio, s);
+    return (prio & 1) ? launch_pp<bf16, 2, 1>(p, prio, s) : launch_pp<bf16, 2, 0>(p, prio, s);
 }
