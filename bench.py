@@ -35,8 +35,8 @@ sys.path.insert(0, ROOT)
 # (SURVEY.md section 8d): D-step 210.40 + G-step 199.34 GFLOP at channel_factor = 1.
 GFLOP_PER_IMAGE = {1: 409.74, 2: 197.75, 0.5: 1239.60}
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}      # dense MFMA peaks, MI355X_MICROARCH.md
-DOMINANT_KERNEL = "conv3x3_pp_kernel<bf16,8> (sp_conv2d_igemm, 3x3, Cout>64, 128 co x 8x32 px tiles, ping-pong schedule)"
-DOMINANT_KERNEL_SYMBOL = "conv3x3_pp_kernel<bf16, 8"
+DOMINANT_KERNEL = "conv3x3_pp_kernel<bf16,2> (sp_conv2d_igemm, 3x3, Cout>64, 128 co x 8x32 px tiles, ping-pong schedule)"
+DOMINANT_KERNEL_SYMBOL = "conv3x3_pp_kernel<bf16, 2"
 TRAFFIC_FILES = ("round3_hbm_traffic_per_kernel.json", "round2_hbm_traffic_per_kernel.json")
 
 
@@ -476,7 +476,7 @@ def main():
                                      "conv_ms_per_step_eager": totals["ms_per_step"], "backward_tflops": totals["backward_tflops"],
                                      "backward_frac": round(totals["backward_tflops"] / peak, 4),
                                      "families": families, "dominant_kernel": dom})
-            traffic, prov = recorded_traffic((DOMINANT_KERNEL_SYMBOL, "conv3x3_tall_kernel<bf16, 2, 8>"))
+            traffic, prov = recorded_traffic((DOMINANT_KERNEL_SYMBOL, "conv3x3_pp_kernel<bf16, 8", "conv3x3_tall_kernel<bf16, 2, 8>"))
             line["roofline"]["traffic"] = traffic
             line["roofline"]["traffic_source"] = prov
         if world == 1 and not args.no_sub_records:

@@ -495,8 +495,8 @@ def _probed(family: str, flops: float, dominant: bool, fn) -> None:
 
 
 def _is_halo128(n, h, w, cout, ksize) -> bool:
-    """Launches that sp_conv2d_igemm routes to the 128 co x 8x32 px tile kernel (conv3x3_tall_kernel<.., 2, 8>, or
-    conv3x3_halo_kernel<.., 128, 3> with SP_CONV_SHORT=0): the kernel with the largest share of a step; mirrors dispatch() in
+    """Launches that sp_conv2d_igemm routes to the 128 co x 8x32 px tile kernel (conv3x3_pp_kernel<bf16, 2>; with SP_CONV_PP=0
+    conv3x3_tall_kernel<.., 2, 8>; fp32: the latter): the kernel with the largest share of a step; mirrors dispatch() in
     csrc/conv_igemm.hip, including the hand-over of some shapes to the 16-row tall kernel."""
     if not (ksize == 3 and cout > 64 and h % 8 == 0 and w % 32 == 0):
         return False
