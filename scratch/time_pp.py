@@ -8,7 +8,7 @@ for cin, cout, hw in [(128, 128, 128), (256, 256, 64), (64, 128, 128)]:
     x = ops.nhwc_empty(B, cin, hw, hw, dt, 'cuda'); x.normal_()
     w = (torch.randn(cout * 9 * cin, device='cuda') * 0.05).to(dt)
     bias = torch.randn(cout, device='cuda'); y = ops.nhwc_empty(B, cout, hw, hw, dt, 'cuda')
-    ws = torch.zeros(256 * 8 * 8, device='cuda')
+    ws = torch.zeros(256 * 8 * 16, device='cuda')
     lib.sp_set_tuning(21, 8); lib.sp_set_tuning(22, int(sys.argv[1]) if len(sys.argv) > 1 else 5)
     p = L.SpConvParams()
     p.x, p.w, p.bias, p.y = x.data_ptr(), w.data_ptr(), bias.data_ptr(), y.data_ptr()
@@ -17,10 +17,12 @@ for cin, cout, hw in [(128, 128, 128), (256, 256, 64), (64, 128, 128)]:
     for _ in range(3):
         L.call("sp_conv2d_igemm", ctypes.byref(p), ops.stream())
     torch.cuda.synchronize()
-    t = ws.view(256, 8, 8)[:, :, :8]
+    t16 = ws.view(256, 8, 16); t = t16[:, :, :8]
     for half, sl in (("waves 0-3", slice(0, 4)), ("waves 4-7", slice(4, 8))):
         m = t[:, sl, :].mean(dim=(0, 1)); tot = m.sum().item()
         print("%d->%d @%d %s: total %.0f cycles | " % (cin, cout, hw, half, tot) + " | ".join("%s %.1f%%" % (n, 100 * v / tot) for n, v in zip(names, m.tolist())))
+    e = t16[:, :, 8:12].mean(dim=(0, 1)).tolist(); items = B * (hw // 8) * (hw // 32) * ((cout + 127) // 128) / 256
+    print("   per item: acc init %.0f | item-end setup %.0f | fragments %.0f | next coordinates %.0f cycles" % tuple(v / items for v in e))
     stages = (B * (hw // 8) * (hw // 32) * ((cout + 127) // 128) / 256) * ((cin + 31) // 32) * 3
     print("   stages per block %.1f -> cycles per stage %.0f" % (stages, t.sum(dim=2).mean().item() / stages))
 lib.sp_set_tuning(21, -1); lib.sp_set_tuning(22, -1)

@@ -83,7 +83,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 // the same on N values with ONE (uniform) branch on `act`: the per-element form above expands to a branch - and an inlined
 // tanhf - per value when it is called in an unrolled loop (7.8 K scalar instructions in the tall convolution kernel)
-template <int N>
+template <int N, bool TANH_OK = true>
 __device__ __forceinline__ void apply_act_vec(float (&v)[N], int act) {
     if (act == SP_ACT_NONE) return;
     if (act == SP_ACT_LRELU) {
@@ -98,7 +98,7 @@ __device__ __forceinline__ void apply_act_vec(float (&v)[N], int act) {
     } else if (act == SP_ACT_RELU) {
 #pragma unroll
         for (int r = 0; r < N; ++r) v[r] = fmaxf(v[r], 0.f);
-    } else if (act == SP_ACT_TANH) {
+    } else if (TANH_OK && act == SP_ACT_TANH) {
 #pragma unroll
         for (int r = 0; r < N; ++r) v[r] = tanhf(v[r]);
     }

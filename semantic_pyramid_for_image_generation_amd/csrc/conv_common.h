@@ -103,13 +103,12 @@ template <> struct Wide16<float> {
         for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(p + 4 * k) = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
     }
 };
-template <typename T>
-__device__ __forceinline__ void conv_epilogue16(const sp_conv_params& p, float (&v)[16], long pix, int co, bool add_bias = true) {
-    T* __restrict__ yg = reinterpret_cast<T*>(p.y);
+// bias / mask / residuals / activation of 16 consecutive channels of one pixel, in place (everything of the epilogue but the store)
+template <typename T, bool TANH_OK = true>
+__device__ __forceinline__ void conv_epilogue16_values(const sp_conv_params& p, float (&v)[16], long off, int co, bool add_bias = true) {
     const T* r1 = reinterpret_cast<const T*>(p.res1);
     const T* r2 = reinterpret_cast<const T*>(p.res2);
     const T* ms = reinterpret_cast<const T*>(p.mask_src);
-    const long off = pix * p.ldy + co;
     float t[16];
     if (p.bias && add_bias) {
         Wide16<float>::ld(p.bias + co, t);
@@ -131,8 +130,13 @@ __device__ __forceinline__ void conv_epilogue16(const sp_conv_params& p, float (
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] += t[r];
     }
-    apply_act_vec<16>(v, p.act);
-    Wide16<T>::st(yg + off, v);
+    apply_act_vec<16, TANH_OK>(v, p.act);
+}
+template <typename T>
+__device__ __forceinline__ void conv_epilogue16(const sp_conv_params& p, float (&v)[16], long pix, int co, bool add_bias = true) {
+    const long off = pix * p.ldy + co;
+    conv_epilogue16_values<T>(p, v, off, co, add_bias);
+    Wide16<T>::st(reinterpret_cast<T*>(p.y) + off, v);
 }
 
 // 2x2 average pooling fused into the epilogue (pool2): the two rows of a pair are two fragments of the SAME lane, the two

@@ -18,12 +18,15 @@
 //        waves 4-7  M(g-1)   L(g)     M(g)     L(g+1)   M(g+1)  ...
 //
 //   * vmcnt is never drained in the loop.  Weights live in a 4-slot ring and are requested THREE stages ahead, the halo of
-//     chunk c+1 during the first two stages of chunk c, and the requests are issued INSIDE the MFMA segment, one LDS-DMA
-//     instruction behind each group of 8 MFMAs (its ~60-150 issue cycles hide behind the wave's own queued matrix work; in the
-//     LOAD segment they made it longer than the partner's MFMA segment).  Every wave issues the same number of wave-instructions per stage
-//     (requests past the end of the block's work, and halo pieces past the end of the tile, go to a dummy LDS kilobyte with an
-//     out-of-range offset = zero fill, no memory traffic), so every wait is `vmcnt(pieces issued since)` with a compile-time
-//     count.  Epilogue stores no longer stall the pipeline head: they are older than nothing the next wait needs.
+//     chunk c+1 during the first two stages of chunk c; the requests sit in the LOAD segment, one LDS-DMA instruction behind
+//     every four fragment reads (the reads queue on the LDS pipe, the requests on the texture path; inside the MFMA segment they
+//     cost the matrix stream ~45 cycles each - measured, SP_TUNE_CONV_PP_PRIO history in profiles/README.md).  Every wave issues
+//     the same number of wave-instructions per stage (requests past the end of the block's work, and halo pieces past the end of
+//     the tile, go to a dummy LDS kilobyte with an out-of-range offset = zero fill, no memory traffic), so every wait is
+//     `vmcnt(pieces issued since)` with a compile-time count.
+//   * item end: BOTH halves run their epilogue in the same barrier interval (the half that runs behind: before the barrier that
+//     follows its last MFMA segment), and the epilogue the launcher can promise whole 16-channel groups for is one pass per
+//     operand over the lane's 64 values (FAST) - see the comments at the kernel and at `item_ends`.
 //   * hazards by construction: a LOAD segment ends with `lgkmcnt(0)` BEFORE its barrier, so when any wave passes barrier k all
 //     LDS reads issued before it have returned; a ring slot is re-requested >= 1 barrier after its last read (WAR), and data is
 //     read >= 1 barrier after the counted wait of EVERY wave that requested a piece of it (RAW; the half that runs ahead reads
@@ -68,9 +71,14 @@ constexpr int pp_group_index(int h, int dr, int rw) {
     return k;
 }
 
-template <typename T, int WCO, int PRIO, bool TIMING = false, bool DMA_IN_L = true>
+// FAST: the epilogue for what the launcher can promise - whole 16-channel groups (Cout % 16 == 0, ldy % 8 == 0), no pooling, no
+// tanh.  The general epilogue (per-lane `wide` test, 4-channel and scalar tails, pooling, an inlined tanh per value and call site) is
+// 18 K instructions in ~1 100 basic blocks around a 1.7 K-instruction loop; measured with compile-time assumptions in its place
+// (scratch: -DPP_ASSUME_SIMPLE), a launch of 128->128 @128^2 drops from 170 K to 148 K cycles per block, 64->128 from 111 K to 92 K.
+template <typename T, int WCO, int PRIO, bool TIMING = false, bool DMA_IN_L = true, bool FAST = false>
 __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int cotiles, int total, int prio) {
     using G = PPGeom<T, WCO>;
+    static_assert(!FAST || sizeof(T) == 2, "FAST epilogue: bf16");
     constexpr int E = G::E, KC = G::KC, CO_T = G::CO_T, WPX = G::WPX, RW = G::RW, NB = G::NB, NFR = G::NFR, HR = G::HR, HP = G::HP, TH = G::TH;
     constexpr int HALO_INSTR = G::HALO_INSTR, HALO_BUF = G::HALO_BUF, HPW = G::HPW, W_BYTES = G::W_BYTES, W_PER = G::W_PER, W_INSTR = G::W_INSTR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -203,20 +211,16 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
 
     const bool bias_in_acc = !G::F8 && p.bias != nullptr && !up && cotiles * CO_T <= PP_BIAS_MAX;   // (SP_F8: the bias follows the scale)
     f32x4_t acc[4][NFR];
-    auto init_acc = [&](bool live, int co0) {
-        uint4 b4[4];
+    // accumulators of an item start at its bias, held in 16 registers that the item's first stage feeds to its MFMAs as the C
+    // operand; the LDS reads for the NEXT item are issued in the epilogue (any LOAD segment's lgkmcnt(0) lands them before use)
+    uint4 b4[4];
+    auto bias_fetch = [&](bool live, int co0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) b4[i] = make_uint4(0, 0, 0, 0);
         if (bias_in_acc && live) {
             const unsigned ba = bias_addr + (unsigned)co0 * 4u;
             lds_rd128<0>(b4[0], ba); lds_rd128<16>(b4[1], ba); lds_rd128<32>(b4[2], ba); lds_rd128<48>(b4[3], ba);
-            wait_lgkm<0>();
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < NFR; ++j)
-                acc[i][j] = f32x4_t{__uint_as_float(b4[i].x), __uint_as_float(b4[i].y), __uint_as_float(b4[i].z), __uint_as_float(b4[i].w)};
     };
 
     // ---- prologue: chunk 0's halo, weight stages 0, 1 and 2
@@ -232,14 +236,15 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the bias copy
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    init_acc(true, cur.co_i * CO_T);
+    bias_fetch(true, cur.co_i * CO_T);
+    wait_lgkm<0>();
     if (half_b) __builtin_amdgcn_s_barrier();               // from here on this half runs one segment behind
 
     if ((prio & 2) && half_b) __builtin_amdgcn_s_setprio(1);
     // TIMING build (diagnostics, SP_TUNE_CONV_PP_PRIO bit 2): cycles per wave in [0] LOAD segment up to the counted wait (fragment
     // reads + DMA issue + LDS latency), [1] the vmcnt wait, [2] barrier after LOAD, [3] MFMA segment, [4] barrier after MFMA,
     // [5] epilogue + item switch; written to p.workspace[(block * 8 + wave) * 8 + k] (fp32 scratch pointer, unused by this kernel)
-    unsigned long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = 0;
     auto stamp = [&](int k) {
         if constexpr (TIMING) {
@@ -258,8 +263,11 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
         const bool item_ends = kc + 1 == kchunks;
         const unsigned hb = (unsigned)((gc & 1) * HALO_BUF);
         const int c0_next = item_ends ? 0 : (kc + 1) * KC;
-        static_for<3>([&](auto sc) {
+        // FIRST: the first stage of an item - the first MFMA into every accumulator takes the bias registers as its C operand
+        // (the item's accumulators are never initialised: 64 moves per wave and item saved)
+        auto stage = [&](auto sc, auto fc) {
             constexpr int st = decltype(sc)::value;        // stage inside the chunk = tap column
+            constexpr bool FIRST = decltype(fc)::value;
             constexpr int TAP_STRIDE = CO_T * 64;
             constexpr int NH = st == 0 ? G::HPS0 : st == 1 ? G::HPS1 : 0, H0 = st == 0 ? 0 : G::HPS0;   // halo pieces requested in this stage
             constexpr int NPIECE = NH + W_PER;
@@ -316,30 +324,117 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int hh = 0; hh < 2; ++hh) Mma<T>::run(a[dr][i], bf[h][hh], acc[i][rr * 2 + hh]);
+                        for (int hh = 0; hh < 2; ++hh) {
+                            f32x4_t c = (FIRST && dr == 0) ? __builtin_bit_cast(f32x4_t, b4[i]) : acc[i][rr * 2 + hh];
+                            Mma<T>::run(a[dr][i], bf[h][hh], c);
+                            acc[i][rr * 2 + hh] = c;
+                        }
                     if constexpr (!DMA_IN_L) piece(std::integral_constant<int, pp_group_index(h, dr, RW)>{});   // behind MFMA group k: request k
                 }
             });
             if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             stamp(3);
-            __builtin_amdgcn_s_barrier();
+            // (item end, the half that runs behind: its epilogue comes BEFORE this barrier - see below)
+            if (!(st == 2 && item_ends && half_b && !(prio & 128))) __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             stamp(4);
             g4 = (g4 + 1) & 3;
-        });
+        };
+        if (kc == 0) stage(std::integral_constant<int, 0>{}, std::true_type{});
+        else stage(std::integral_constant<int, 0>{}, std::false_type{});
+        stage(std::integral_constant<int, 1>{}, std::false_type{});
+        stage(std::integral_constant<int, 2>{}, std::false_type{});
         if (item_ends) {
+            // BOTH epilogues in one barrier interval.  After its last MFMA segment the leading half passes the barrier, runs its
+            // epilogue and the next item's first LOAD segment; the other half is in its last MFMA segment meanwhile and would then
+            // wait ~3 000 cycles at the barrier - and hold the leading half up for just as long one interval later, with its own
+            // epilogue.  So it runs its epilogue right behind its MFMAs, in front of the barrier: the interval takes
+            // max(M + E, E + L) instead of two intervals of E + L each.
             const int n = cur.n, ty0 = cur.ty_i * TH, tx0 = cur.tx_i * PP_TW, co0 = cur.co_i * CO_T;
             const long pix0 = ((long)n * H + ty0 + RW * wpx) * W + tx0 + (lane & 15);
             const int co_b = co0 + wco * 64 + (lane >> 4) * 16;          // this lane's 16 consecutive channels
-            const bool wide = vec_ok && (p.ldy & 7) == 0 && co_b + 16 <= p.cout;
+            const bool wide = FAST ? co_b < p.cout : vec_ok && (p.ldy & 7) == 0 && co_b + 16 <= p.cout;
             if (up) {                                                    // the 1/4 of the average-pooling gradient
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < NFR; ++j) acc[i][j] *= 0.25f;
             }
-            if constexpr (G::F8) {
+            stamp(9);
+            if constexpr (FAST) {
+                // ONE pass per epilogue operand over the whole 64-value tile of the lane (a handful of uniform branches per item, the
+                // eight loads of an operand in flight together) - the per-fragment form (each fragment: its own tests for bias / mask /
+                // residuals / activation, its own load -> wait) cost ~640 cycles per fragment, 5x its VALU work
+                if (wide) {
+                    const long off0 = pix0 * p.ldy + co_b;
+                    auto foff = [&](int j) { return off0 + ((long)(j >> 1) * W + (j & 1) * 16) * p.ldy; };
+                    if (!bias_in_acc && p.bias != nullptr) {
+                        float t[16];
+                        Wide16<float>::ld(p.bias + co_b, t);
+#pragma unroll
+                        for (int c = 0; c < 16; ++c)
+#pragma unroll
+                            for (int jj = 0; jj < NFR; ++jj) acc[c >> 2][jj][c & 3] += t[c];
+                    }
+                    // channel c = 4 i + r of the lane's 16 is acc[i][j][r]; word k of the 32 bytes of (pixel, 16 channels) = channels 2k, 2k + 1
+                    auto with_operand = [&](const T* src, auto&& apply) {
+                        uint4 t[NFR][2];
+#pragma unroll
+                        for (int jj = 0; jj < NFR; ++jj) {
+                            const T* q = src + foff(jj);
+                            t[jj][0] = *reinterpret_cast<const uint4*>(q);
+                            t[jj][1] = *reinterpret_cast<const uint4*>(q + 8);
+                        }
+#pragma unroll
+                        for (int jj = 0; jj < NFR; ++jj)
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                const uint4& u = t[jj][k >> 2];
+                                const uint32_t w = (k & 3) == 0 ? u.x : (k & 3) == 1 ? u.y : (k & 3) == 2 ? u.z : u.w;
+                                acc[k >> 1][jj][2 * (k & 1)] = apply(acc[k >> 1][jj][2 * (k & 1)], __uint_as_float(w << 16));
+                                acc[k >> 1][jj][2 * (k & 1) + 1] = apply(acc[k >> 1][jj][2 * (k & 1) + 1], __uint_as_float(w & 0xffff0000u));
+                            }
+                    };
+                    if (p.mask_src != nullptr) {
+                        const float slope = p.mask_neg_slope;
+                        with_operand(reinterpret_cast<const T*>(p.mask_src), [&](float a, float t) { return a * (t > 0.f ? 1.f : slope); });
+                    }
+                    if (p.res1 != nullptr) with_operand(reinterpret_cast<const T*>(p.res1), [](float a, float t) { return a + t; });
+                    if (p.res2 != nullptr) with_operand(reinterpret_cast<const T*>(p.res2), [](float a, float t) { return a + t; });
+                    if (p.act == SP_ACT_LRELU) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int jj = 0; jj < NFR; ++jj) {
+                                const f32x4_t sv = acc[i][jj] * 0.2f;                        // two packed multiplies
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const float av = acc[i][jj][r], s1 = sv[r];
+                                    float mv;
+                                    asm("v_max_f32 %0, %1, %2" : "=v"(mv) : "v"(av), "v"(s1));   // (apply_act_vec, common.h)
+                                    acc[i][jj][r] = mv;
+                                }
+                            }
+                    } else if (p.act == SP_ACT_RELU) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int jj = 0; jj < NFR; ++jj)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) acc[i][jj][r] = fmaxf(acc[i][jj][r], 0.f);
+                    }
+                    static_for<NFR>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        unsigned w8[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) w8[k] = f32x2_to_bf16x2(acc[k >> 1][j][2 * (k & 1)], acc[k >> 1][j][2 * (k & 1) + 1]);
+                        T* q = reinterpret_cast<T*>(p.y) + foff(j);
+                        *reinterpret_cast<uint4*>(q) = make_uint4(w8[0], w8[1], w8[2], w8[3]);
+                        *reinterpret_cast<uint4*>(q + 8) = make_uint4(w8[4], w8[5], w8[6], w8[7]);
+                    });
+                }
+            } else if constexpr (G::F8) {
                 // SP_F8 epilogue: v = relu(acc * scale[co] + bias[co]) (the 2x2 maximum first: it commutes with the positive scale,
                 // the bias and the ReLU), stored as bf16 and / or re-quantised to e4m3 for the next layer; running max for its scale
                 uint4 sc4[4], bi4[4];
@@ -441,12 +536,14 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
                     }
                 }
             });
+            stamp(10);
             kc = 0;
             cur = nxt;
             nxt = advance(nxt);
             stamp(5);
-            init_acc(more_chunks, cur.co_i * CO_T);
+            bias_fetch(more_chunks, cur.co_i * CO_T);       // (after the epilogue's own reads of the bias / scale tables)
             stamp(8);
+            if (half_b && !(prio & 128)) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
         } else {
             ++kc;
         }
@@ -470,20 +567,23 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
     }
     if constexpr (TIMING) {
         if (lane == 0 && p.workspace != nullptr) {
-            float* out = reinterpret_cast<float*>(p.workspace) + ((long)blockIdx.x * 8 + wave) * 8;
-            for (int k = 0; k < 8; ++k) out[k] = (float)tacc[k];
-            out[5] += (float)tacc[8];
+            // 16 floats per wave: [0..7] as above ([5] = the whole item switch), [8] accumulator init, [9] item-end setup (the 1/4 of
+            // a pooling gradient), [10] the fragments (values, packing, stores), [11] coordinates of the next item
+            float* out = reinterpret_cast<float*>(p.workspace) + ((long)blockIdx.x * 8 + wave) * 16;
+            for (int k = 0; k < 12; ++k) out[k] = (float)tacc[k];
+            out[11] = out[5];
+            out[5] += (float)(tacc[8] + tacc[9] + tacc[10]);
         }
     }
 }
 
-template <typename T, int WCO, int PRIO, bool TIMING = false, bool DMA_IN_L = true>
+template <typename T, int WCO, int PRIO, bool TIMING = false, bool DMA_IN_L = true, bool FAST = false>
 int launch_pp(const sp_conv_params& p, int prio, hipStream_t s) {
     using G = PPGeom<T, WCO>;
     constexpr int TH = G::TH;
     static_assert(G::LDS <= 163840, "LDS budget");
     static bool attr_set = false;
-    auto kern = conv3x3_pp_kernel<T, WCO, PRIO, TIMING, DMA_IN_L>;
+    auto kern = conv3x3_pp_kernel<T, WCO, PRIO, TIMING, DMA_IN_L, FAST>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
         if (e != hipSuccess) { sp_set_error("hipFuncSetAttribute(LDS=%d) failed: %s", G::LDS, hipGetErrorString(e)); return SP_ERR_LAUNCH; }
@@ -511,10 +611,13 @@ int sp_conv_pp_launch(const sp_conv_params& p, int th, hipStream_t s) {
     if (p.dtype != SP_BF16 || p.ksize != 3 || p.h % th != 0 || p.w_ % PP_TW != 0) return 1;
     const long esz = 2;
     if ((long)p.n * p.h * p.w_ * p.cin_p * esz >= (1L << 30) || (long)p.cout * 9 * p.cin_p * esz >= (1L << 30)) return 1;
+    // SP_TUNE_CONV_PP_PRIO (diagnostics / A-B): bit 2 = the TIMING build, bit 4 = the general epilogue everywhere, bit 7 = the two
+    // halves' epilogues in separate barrier intervals (the round-3 mid-state)
     const int prio = sp_tune(SP_TUNE_CONV_PP_PRIO, 1);
-    if (th == 16 && p.cout <= 64) return (prio & 1) ? launch_pp<bf16, 1, 1>(p, prio, s) : launch_pp<bf16, 1, 0>(p, prio, s);   // 64 co x 16x32 px
+    const bool fast = !(prio & 16) && p.pool2 == 0 && (p.cout & 15) == 0 && (p.ldy & 7) == 0 && p.act != SP_ACT_TANH;
+    if (th == 16 && p.cout <= 64)                          // 64 co x 16x32 px
+        return fast ? launch_pp<bf16, 1, 1, false, true, true>(p, prio, s) : launch_pp<bf16, 1, 1>(p, prio, s);
     if (th != 8 || p.cout <= 64) return 1;
-    if (prio & 4) return (prio & 8) ? launch_pp<bf16, 2, 1, true, false>(p, prio, s) : launch_pp<bf16, 2, 1, true, true>(p, prio, s);
-    if (prio & 8) return launch_pp<bf16, 2, 1, false, false>(p, prio, s);
-    return (prio & 1) ? launch_pp<bf16, 2, 1>(p, prio, s) : launch_pp<bf16, 2, 0>(p, prio, s);
+    if (prio & 4) return fast ? launch_pp<bf16, 2, 1, true, true, true>(p, prio, s) : launch_pp<bf16, 2, 1, true>(p, prio, s);
+    return fast ? launch_pp<bf16, 2, 1, false, true, true>(p, prio, s) : launch_pp<bf16, 2, 1>(p, prio, s);
 }
