@@ -238,7 +238,13 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
     __builtin_amdgcn_sched_barrier(0);
     bias_fetch(true, cur.co_i * CO_T);
     wait_lgkm<0>();
-    if (half_b) __builtin_amdgcn_s_barrier();               // from here on this half runs one segment behind
+    // A/B switch (SP_TUNE_CONV_PP_PRIO bit 8): ONE barrier per stage - the leading half synchronises only behind its MFMA
+    // segment, the other half only behind its LOAD segment, an interval is  L(g) M(g)  for one half and  M(g-1) L(g)  for the
+    // other; every hazard still has a barrier in between and an s_barrier release (~220 cycles) is paid once per stage.  Measured:
+    // the half that multiplies first in an interval loses the matrix pipe to its partner's tail (its MFMA segment 780 -> 1 050
+    // cycles); full step 18.19 vs 18.01 ms with two barriers.  Default: two.
+    const bool two_barriers = (prio & 256) == 0;
+    if (half_b && two_barriers) __builtin_amdgcn_s_barrier();   // (two barriers: from here on this half runs one segment behind)
 
     if ((prio & 2) && half_b) __builtin_amdgcn_s_setprio(1);
     // TIMING build (diagnostics, SP_TUNE_CONV_PP_PRIO bit 2): cycles per wave in [0] LOAD segment up to the counted wait (fragment
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
             stamp(1);
             wait_lgkm<0>();                                 // every LDS read of this wave has returned before it signals
             stamp(7);
-            __builtin_amdgcn_s_barrier();
+            if (two_barriers || half_b) __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             stamp(2);
             // ================= MFMA segment, with this stage's requests behind its MFMA groups =================
@@ -336,7 +342,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
             __builtin_amdgcn_sched_barrier(0);
             stamp(3);
             // (item end, the half that runs behind: its epilogue comes BEFORE this barrier - see below)
-            if (!(st == 2 && item_ends && half_b && !(prio & 128))) __builtin_amdgcn_s_barrier();
+            if (two_barriers ? !(st == 2 && item_ends && half_b && !(prio & 128)) : !half_b) __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             stamp(4);
             g4 = (g4 + 1) & 3;
@@ -543,12 +549,12 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
             stamp(5);
             bias_fetch(more_chunks, cur.co_i * CO_T);       // (after the epilogue's own reads of the bias / scale tables)
             stamp(8);
-            if (half_b && !(prio & 128)) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+            if (half_b && two_barriers && !(prio & 128)) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
         } else {
             ++kc;
         }
     }
-    if (!half_b) __builtin_amdgcn_s_barrier();              // the barrier the other half passes after its last MFMA segment
+    if (!half_b && two_barriers) __builtin_amdgcn_s_barrier();  // the barrier the other half passes after its last MFMA segment
     if constexpr (G::F8) {
         // one atomic per BLOCK on the running maximum (per item and wave they serialise on one L2 word: 10 K atomics = 100+ us)
         if (p.y8_amax != nullptr) {
