@@ -24,5 +24,9 @@ for cin, cout, hw in [(128, 128, 128), (256, 256, 64), (64, 128, 128)]:
     e = t16[:, :, 8:12].mean(dim=(0, 1)).tolist(); items = B * (hw // 8) * (hw // 32) * ((cout + 127) // 128) / 256
     print("   per item: acc init %.0f | item-end setup %.0f | fragments %.0f | next coordinates %.0f cycles" % tuple(v / items for v in e))
     stages = (B * (hw // 8) * (hw // 32) * ((cout + 127) // 128) / 256) * ((cin + 31) // 32) * 3
+    if (int(sys.argv[1]) if len(sys.argv) > 1 else 5) & 512:
+        mid = (B * (hw // 8) * (hw // 32) * ((cout + 127) // 128) / 256) * max((cin + 31) // 32 - 2, 0) * 3
+        m = t.mean(dim=(0, 1)).tolist()
+        print("   MID chunks only (%d stages): per stage " % mid + " | ".join("%s %.0f" % (n, v / max(mid, 1)) for n, v in zip(names, m)))
     print("   stages per block %.1f -> cycles per stage %.0f" % (stages, t.sum(dim=2).mean().item() / stages))
 lib.sp_set_tuning(21, -1); lib.sp_set_tuning(22, -1)

@@ -37,6 +37,9 @@
 
 namespace {
 
+#ifndef PP_HOIST
+#define PP_HOIST 1
+#endif
 constexpr int PP_TW = 32;
 constexpr int PP_NUM_CU = 256;                 // MI355X
 constexpr int PP_BIAS_MAX = 1024;              // output channels whose bias fits the LDS copy
@@ -252,10 +255,11 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
     // [5] epilogue + item switch; written to p.workspace[(block * 8 + wave) * 8 + k] (fp32 scratch pointer, unused by this kernel)
     unsigned long long tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = 0;
+    bool stamp_on = true;
     auto stamp = [&](int k) {
         if constexpr (TIMING) {
             const unsigned long long t = __builtin_readcyclecounter();
-            tacc[k] += t - tprev;
+            if (!(prio & 512) || stamp_on) tacc[k] += t - tprev;     // bit 9: only the chunks in the middle of an item
             tprev = t;
         }
     };
@@ -267,12 +271,19 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
     for (int gc = 0; gc < nchunks; ++gc) {
         const bool more_chunks = gc + 1 < nchunks;
         const bool item_ends = kc + 1 == kchunks;
+        if constexpr (TIMING) stamp_on = kc != 0 && !item_ends;
         const unsigned hb = (unsigned)((gc & 1) * HALO_BUF);
         const int c0_next = item_ends ? 0 : (kc + 1) * KC;
         // FIRST: the first stage of an item - the first MFMA into every accumulator takes the bias registers as its C operand
         // (the item's accumulators are never initialised: 64 moves per wave and item saved)
+        uint4 bf[NB][2];
         auto stage = [&](auto sc, auto fc) {
             constexpr int st = decltype(sc)::value;        // stage inside the chunk = tap column
+            // HOIST: the pixel fragments of stages 1 and 2 are read at the END of the previous stage's MFMA segment, in front of its
+            // barrier: the chunk's halo is complete in LDS since the chunk began (no hazard), the LDS pipe is idle while the barrier
+            // releases, and the LOAD segment of two stages in three shrinks from 20 to 12 reads - below the MFMA segment it pairs with
+            constexpr bool B_HERE = !PP_HOIST || st == 0;
+            constexpr int NREAD = B_HERE ? 12 + 2 * NB : 12;
             constexpr bool FIRST = decltype(fc)::value;
             constexpr int TAP_STRIDE = CO_T * 64;
             constexpr int NH = st == 0 ? G::HPS0 : st == 1 ? G::HPS1 : 0, H0 = st == 0 ? 0 : G::HPS0;   // halo pieces requested in this stage
@@ -280,7 +291,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
             const unsigned ab = a_addr + (unsigned)(g4 * W_BYTES);
             const unsigned bb = b_addr[st] + hb;
             const unsigned bo = HP == 36 ? (bb ^ 32u) : bb; // odd halo rows (pitch 36): swizzle key flipped in bit 1
-            uint4 a[3][4], bf[NB][2];
+            uint4 a[3][4];
             // ================= LOAD segment: every fragment of the stage =================
             const int ws = (g4 + 3) & 3;                    // slot of stage g + 3 = slot of stage g - 1 (its reads ended >= two barriers ago)
             auto piece = [&](auto kc_) {                    // request number k of this stage: halo of the next chunk, then weights of stage g + 3
@@ -293,13 +304,13 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
             }
             // DMA_IN_L: one request behind every four fragment reads - the reads queue on the LDS pipe, the requests on the texture
             // path, so neither waits for the other's queue to drain
-            static_for<((12 + 2 * NB + 3) / 4 > NPIECE ? (12 + 2 * NB + 3) / 4 : NPIECE)>([&](auto qc) {
+            static_for<((NREAD + 3) / 4 > NPIECE ? (NREAD + 3) / 4 : NPIECE)>([&](auto qc) {
                 constexpr int q0 = decltype(qc)::value * 4;
                 static_for<4>([&](auto rc) {
                     constexpr int r = q0 + decltype(rc)::value;     // read number: 0..11 = A (tap row r / 4, fragment r % 4), then B rows
                     if constexpr (r < 12) {
                         lds_rd128<(r / 4) * TAP_STRIDE + (r % 4) * 256>(a[r / 4][r % 4], ab);
-                    } else if constexpr (r < 12 + 2 * NB) {
+                    } else if constexpr (r < NREAD) {
                         constexpr int h = (r - 12) / 2, hh = (r - 12) % 2;
                         lds_rd128<h * (HP * 64) + hh * 1024>(bf[h][hh], (h & 1) ? bo : bb);
                     }
@@ -340,6 +351,13 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
             });
             if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PP_HOIST && st < 2) {
+                const unsigned bn = b_addr[st + 1] + hb;
+                static_for<2 * NB>([&](auto rc) {
+                    constexpr int h = decltype(rc)::value / 2, hh = decltype(rc)::value % 2;
+                    lds_rd128<h * (HP * 64) + hh * 1024>(bf[h][hh], bn);
+                });
+            }
             stamp(3);
             // (item end, the half that runs behind: its epilogue comes BEFORE this barrier - see below)
             if (two_barriers ? !(st == 2 && item_ends && half_b && !(prio & 128)) : !half_b) __builtin_amdgcn_s_barrier();
