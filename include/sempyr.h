@@ -65,13 +65,14 @@ int sp_version(void);
  *   SP_TUNE_CONV_PP          bf16 3x3 layers with Cout > 64: 0 = conv3x3_tall_kernel (round 2's lockstep schedule), 1 = the ping-pong
  *                            schedule of conv_pp.hip, tile height by round count (default), 8 / 16 = force that tile height
  *   SP_TUNE_WGRAD_PP         0 = the 3x3 weight gradient of wide maps stays on the 4-wave row walker (default 1: its ping-pong form)
+ *   SP_TUNE_BN_ITERS         pixels per thread of the elementwise BatchNorm passes (grid sizing; default 2)
  *   SP_TUNE_CONV_PP_PRIO     bit 0: s_setprio 1 around every MFMA segment of the ping-pong kernel (default 1); bit 1: static priority 1
  *                            for the second-dispatched half of the block */
 enum { SP_TUNE_CONV_TALL = 0, SP_TUNE_IGEMM_DMA = 1, SP_TUNE_WGRAD_ROWS = 2, SP_TUNE_DETERMINISTIC = 3,
        SP_TUNE_SPLITK_TARGET = 4, SP_TUNE_SPLITK_MINSTEPS = 5, SP_TUNE_CONV1X1_DIRECT = 6, SP_TUNE_CONV_SHORT = 7,
        SP_TUNE_WGRAD9_BLOCKS = 8, SP_TUNE_WGRAD_BLOCKS = 9, SP_TUNE_WGRAD_MINSTEPS = 10, SP_TUNE_WGRAD_SMALL_M = 11,
        SP_TUNE_WGRAD_K1_TILE64 = 12, SP_TUNE_WGRAD_ROWS_THIN = 13, SP_TUNE_WGRAD_ROWS_BLOCKS = 14, SP_TUNE_WGRAD_ROWS_SLABS = 15,
-       SP_TUNE_CONV_STAGGER = 16, SP_TUNE_CONV1X1_SPLITK = 17, SP_TUNE_WGRAD1X1 = 18, SP_TUNE_CONV_CIN8 = 19, SP_TUNE_CONV_THINCO = 20, SP_TUNE_CONV_PP = 21, SP_TUNE_CONV_PP_PRIO = 22, SP_TUNE_WGRAD_PP = 23, SP_TUNE_COUNT = 24 };
+       SP_TUNE_CONV_STAGGER = 16, SP_TUNE_CONV1X1_SPLITK = 17, SP_TUNE_WGRAD1X1 = 18, SP_TUNE_CONV_CIN8 = 19, SP_TUNE_CONV_THINCO = 20, SP_TUNE_CONV_PP = 21, SP_TUNE_CONV_PP_PRIO = 22, SP_TUNE_WGRAD_PP = 23, SP_TUNE_BN_ITERS = 24, SP_TUNE_COUNT = 25 };
 int sp_set_tuning(int32_t key, int32_t value);
 const char* sp_last_error_string(void);
 

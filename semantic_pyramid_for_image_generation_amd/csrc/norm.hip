@@ -22,7 +22,22 @@ struct Affine {
         if (emb) { const float* row = emb + (long)cls[n] * 2 * C; s = row[c]; b = row[C + c]; }
         else { s = gamma ? gamma[c] : 1.f; b = beta ? beta[c] : 0.f; }
     }
+    // V consecutive channels (c % 4 == 0, C % 4 == 0: 16-byte loads - one per four channels instead of one per channel and array)
+    template <int V>
+    __device__ __forceinline__ void getv(int n, int c, int C, float (&s)[V], float (&b)[V]) const;
 };
+template <int V> __device__ __forceinline__ void ldv(const float* p, float (&o)[V]) {
+#pragma unroll
+    for (int k = 0; k < V / 4; ++k) { const float4 t = *reinterpret_cast<const float4*>(p + 4 * k); o[4 * k] = t.x; o[4 * k + 1] = t.y; o[4 * k + 2] = t.z; o[4 * k + 3] = t.w; }
+}
+template <int V>
+__device__ __forceinline__ void Affine::getv(int n, int c, int C, float (&s)[V], float (&b)[V]) const {
+    if (emb) { const float* row = emb + (long)cls[n] * 2 * C; ldv<V>(row + c, s); ldv<V>(row + C + c, b); return; }
+#pragma unroll
+    for (int r = 0; r < V; ++r) { s[r] = 1.f; b[r] = 0.f; }
+    if (gamma) ldv<V>(gamma + c, s);
+    if (beta) ldv<V>(beta + c, b);
+}
 
 // thread layout: lanes_per_pix channel groups side by side, pix_par pixels per block step
 struct Lay { int cg, pl, lanes_per_pix, pix_par; };
@@ -133,12 +148,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
         const int c = (cbase + L.cg) * V;
         if (c >= C || L.pl >= L.pix_par) continue;
         float a[V], b[V];                                    // y = a * x + b
+        {
+            float mu[V], is[V];
+            aff.template getv<V>(n, c, C, a, b);
+            ldv<V>(mean + c, mu); ldv<V>(invstd + c, is);
 #pragma unroll
-        for (int r = 0; r < V; ++r) {
-            float sc, bi;
-            aff.get(n, c + r, C, sc, bi);
-            a[r] = sc * invstd[c + r];
-            b[r] = bi - mean[c + r] * a[r];
+            for (int r = 0; r < V; ++r) { a[r] *= is[r]; b[r] -= mu[r] * a[r]; }
         }
 #pragma unroll 4
         for (long p = (long)blockIdx.x * L.pix_par + L.pl; p < hw; p += (long)gridDim.x * L.pix_par) {
@@ -218,8 +233,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         for (int r = 0; r < V; ++r) { a[r] = 0.f; b[r] = 0.f; }
         if (live) {
             float sc[V], bi[V], mu[V], is[V];
-#pragma unroll
-            for (int r = 0; r < V; ++r) { aff.get(n, c + r, C, sc[r], bi[r]); mu[r] = mean[c + r]; is[r] = invstd[c + r]; }
+            aff.template getv<V>(n, c, C, sc, bi);
+            ldv<V>(mean + c, mu); ldv<V>(invstd + c, is);
 #pragma unroll 2
             for (long p = (long)blockIdx.x * L.pix_par + L.pl; p < hw; p += (long)gridDim.x * L.pix_par) {
                 float d[V], v[V];
@@ -331,11 +346,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         const int c = (cbase + L.cg) * V;
         if (c >= C || L.pl >= L.pix_par) continue;
         float sc[V], bi[V], mu[V], is[V], k1[V], k2[V];
-#pragma unroll
-        for (int r = 0; r < V; ++r) {
-            aff.get(n, c + r, C, sc[r], bi[r]);
-            mu[r] = mean[c + r]; is[r] = invstd[c + r]; k1[r] = c1[c + r]; k2[r] = c2[c + r];
-        }
+        aff.template getv<V>(n, c, C, sc, bi);
+        ldv<V>(mean + c, mu); ldv<V>(invstd + c, is); ldv<V>(c1 + c, k1); ldv<V>(c2 + c, k2);
 #pragma unroll 4
         for (long p = (long)blockIdx.x * L.pix_par + L.pl; p < hw; p += (long)gridDim.x * L.pix_par) {
             float d[V], v[V];
@@ -355,6 +367,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 
 inline int ew_grid(long items) { long b = (items + 255) / 256; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); }
 
+// elementwise passes: blocks per sample so that a thread walks ~iters pixels (SP_TUNE_BN_ITERS)
+inline int apply_blocks(long hw, int c, int v, int n) {
+    const int groups = c / v, lanes = groups < 256 ? groups : 256, pix_par = 256 / lanes;
+    const int iters = sp_tune(SP_TUNE_BN_ITERS, 2);      // 2 / 4 / 8 / 16 / 32 measured (scratch/bw_probe.py): 2 is at the rate of a device copy
+    long bx = (hw + (long)pix_par * iters - 1) / ((long)pix_par * iters);
+    if (bx * n > 4096) bx = 4096 / n > 0 ? 4096 / n : 1;
+    if (bx < 1) bx = 1;
+    return (int)bx;
+}
 inline int stat_blocks(long pixels, int c, int v) {
     const int groups = c / v, lanes = groups < 256 ? groups : 256, pix_par = 256 / lanes;
     long blocks = pixels / ((long)pix_par * 8);
@@ -403,9 +424,7 @@ extern "C" int sp_bn_apply(const void* x, void* y, int32_t n, int64_t hw, int32_
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     Affine aff{gamma, beta, emb, cls};
     const int v = (dtype == SP_BF16 && c % 8 == 0) ? 8 : 4;
-    int bx = stat_blocks(hw, c, v) * 4;
-    if ((long)bx * n > 4096) bx = 4096 / n > 0 ? 4096 / n : 1;
-    const dim3 g(bx, n);
+    const dim3 g(apply_blocks(hw, c, v, n), n);
     if (dtype == SP_F32) hipLaunchKernelGGL((bn_apply_kernel<float, 4>), g, dim3(256), 0, s, (const float*)x, (float*)y, (long)hw, c, mean, invstd, aff, act);
     else if (v == 8) hipLaunchKernelGGL((bn_apply_kernel<bf16, 8>), g, dim3(256), 0, s, (const bf16*)x, (bf16*)y, (long)hw, c, mean, invstd, aff, act);
     else hipLaunchKernelGGL((bn_apply_kernel<bf16, 4>), g, dim3(256), 0, s, (const bf16*)x, (bf16*)y, (long)hw, c, mean, invstd, aff, act);
@@ -452,9 +471,7 @@ extern "C" int sp_bn_backward(const void* dy, const void* x, void* dx, int32_t n
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sp_div_up(c, FIN_CL)), dim3(256), 0, s, partials, nparts, n, c, pixels, aff, c_tmp, c_tmp + c,
                        dgamma, dbeta, demb, num_classes);
     SP_LAUNCH_CHECK();
-    int bx = stat_blocks(hw, c, v) * 4;
-    if ((long)bx * n > 4096) bx = 4096 / n > 0 ? 4096 / n : 1;
-    const dim3 g(bx, n);
+    const dim3 g(apply_blocks(hw, c, v, n), n);
     if (dtype == SP_F32) hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 4>), g, dim3(256), 0, s, (const float*)dy, (const float*)x, (float*)dx, (long)hw, c, mean, invstd, aff, act, c_tmp, c_tmp + c);
     else if (v == 8) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, 8>), g, dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, (bf16*)dx, (long)hw, c, mean, invstd, aff, act, c_tmp, c_tmp + c);
     else hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, 4>), g, dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, (bf16*)dx, (long)hw, c, mean, invstd, aff, act, c_tmp, c_tmp + c);
