@@ -215,7 +215,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
     const bool bias_in_acc = !G::F8 && p.bias != nullptr && !up && cotiles * CO_T <= PP_BIAS_MAX;   // (SP_F8: the bias follows the scale)
     f32x4_t acc[4][NFR];
     // accumulators of an item start at its bias, held in 16 registers that the item's first stage feeds to its MFMAs as the C
-    // operand; the LDS reads for the NEXT item are issued in the epilogue (any LOAD segment's lgkmcnt(0) lands them before use)
+    // operand; the LDS reads for the NEXT item are issued (and waited for) at the end of the epilogue
     uint4 b4[4];
     auto bias_fetch = [&](bool live, int co0) {
 #pragma unroll
@@ -223,6 +223,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
         if (bias_in_acc && live) {
             const unsigned ba = bias_addr + (unsigned)co0 * 4u;
             lds_rd128<0>(b4[0], ba); lds_rd128<16>(b4[1], ba); lds_rd128<32>(b4[2], ba); lds_rd128<48>(b4[3], ba);
+            wait_lgkm<0>();                                 // (same straight-line region: see the rule at the hoisted fragment reads)
         }
     };
 
@@ -240,7 +241,6 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     bias_fetch(true, cur.co_i * CO_T);
-    wait_lgkm<0>();
     // A/B switch (SP_TUNE_CONV_PP_PRIO bit 8): ONE barrier per stage - the leading half synchronises only behind its MFMA
     // segment, the other half only behind its LOAD segment, an interval is  L(g) M(g)  for one half and  M(g-1) L(g)  for the
     // other; every hazard still has a barrier in between and an s_barrier release (~220 cycles) is paid once per stage.  Measured:
@@ -357,6 +357,12 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
                     constexpr int h = decltype(rc)::value / 2, hh = decltype(rc)::value % 2;
                     lds_rd128<h * (HP * 64) + hh * 1024>(bf[h][hh], bn);
                 });
+                // RULE for every asm LDS read in this file: its lgkmcnt(0) follows in the same straight-line region.  The compiler
+                // does not know that the destination registers are written LATER: with a branch or a barrier in between it reused
+                // registers of a read still in flight for address arithmetic (values it considered dead on that path), and the
+                // late data overwrote them - one wrong launch in a few hundred.  Here the wait costs nothing: the wave is about
+                // to idle at the barrier for longer than an LDS round trip.
+                wait_lgkm<0>();
             }
             stamp(3);
             // (item end, the half that runs behind: its epilogue comes BEFORE this barrier - see below)
@@ -477,6 +483,9 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
                 uint8_t* y8 = reinterpret_cast<uint8_t*>(p.y8);
                 const bool relu = p.act == SP_ACT_RELU;
                 auto finish = [&](float (&v)[16], long opix) {          // one pixel x 16 channels of the (pooled) output
+                    // a co-tile past Cout (Cout % 128 != 0: the launcher guarantees Cout % 16 == 0) has whole 16-channel groups
+                    // outside the tensor: they must not be stored - they would land on channels 0.. of the NEXT pixel
+                    if (co_b >= p.cout) return;
 #pragma unroll
                     for (int c = 0; c < 16; ++c) {
                         v[c] = v[c] * sc[c] + bi[c];

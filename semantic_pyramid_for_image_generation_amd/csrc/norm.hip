@@ -175,42 +175,55 @@ template <typename T, int V>
 __global__ __launch_bounds__(256) void bn_apply_upsample2_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C,
                                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                  Affine aff, int act) {
+    // grid (column slabs, N * OH): a block owns (part of) ONE output row, so the sample, the two source rows and the row weight
+    // are block-uniform, and a thread keeps one channel group: its parameters are loaded once (16-byte loads), the loop body is
+    // four loads -> fma / activation -> blend -> store without any integer division (the flat-index form decoded (n, oh, ow, c)
+    // per output vector and reloaded 4 V scalars: 0.36 TB/s)
     const int OH = 2 * H, OW = 2 * W;
     const float sh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
     const float sw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
-    const int vpp = C / V;
-    const long total = (long)N * OH * OW * vpp;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % vpp) * V;
-        const long pp = i / vpp;
-        const int ow = (int)(pp % OW);
-        const long q = pp / OW;
-        const int oh = (int)(q % OH), n = (int)(q / OH);
+    for (int row = blockIdx.y; row < N * OH; row += gridDim.y) {
+    const int n = row / OH, oh = row - n * OH;
+    const float fh = sh * oh;
+    const int h0 = (int)fh;
+    const int h1 = h0 + (h0 < H - 1 ? 1 : 0);
+    const float lh = fh - h0;
+    const int ngroups = C / V;
+    const Lay L = make_lay(ngroups);
+    for (int cbase = 0; cbase < ngroups; cbase += L.lanes_per_pix) {
+        const int c = (cbase + L.cg) * V;
+        if (c >= C || L.pl >= L.pix_par) continue;
         float a[V], b[V];
+        {
+            float mu[V], is[V];
+            aff.template getv<V>(n, c, C, a, b);
+            ldv<V>(mean + c, mu); ldv<V>(invstd + c, is);
 #pragma unroll
-        for (int r = 0; r < V; ++r) {
-            float sc, bi;
-            aff.get(n, c + r, C, sc, bi);
-            a[r] = sc * invstd[c + r];
-            b[r] = bi - mean[c + r] * a[r];
+            for (int r = 0; r < V; ++r) { a[r] *= is[r]; b[r] -= mu[r] * a[r]; }
         }
-        const float fh = sh * oh, fw = sw * ow;
-        const int h0 = (int)fh, w0 = (int)fw;
-        const int h1 = h0 + (h0 < H - 1 ? 1 : 0), w1 = w0 + (w0 < W - 1 ? 1 : 0);
-        const float lh = fh - h0, lw = fw - w0;
-        const T* base = x + (long)n * H * W * C + c;
-        float v00[V], v01[V], v10[V], v11[V], o[V];
-        VecIO<T, V>::ld(base + ((long)h0 * W + w0) * C, v00);
-        VecIO<T, V>::ld(base + ((long)h0 * W + w1) * C, v01);
-        VecIO<T, V>::ld(base + ((long)h1 * W + w0) * C, v10);
-        VecIO<T, V>::ld(base + ((long)h1 * W + w1) * C, v11);
+        const T* r0 = x + ((long)n * H + h0) * W * C + c;
+        const T* r1 = x + ((long)n * H + h1) * W * C + c;
+        T* yr = y + ((long)n * OH + oh) * OW * C + c;
+#pragma unroll 2
+        for (int ow = blockIdx.x * L.pix_par + L.pl; ow < OW; ow += gridDim.x * L.pix_par) {
+            const float fw = sw * ow;
+            const int w0 = (int)fw;
+            const int w1 = w0 + (w0 < W - 1 ? 1 : 0);
+            const float lw = fw - w0;
+            float v00[V], v01[V], v10[V], v11[V], o[V];
+            VecIO<T, V>::ld(r0 + (long)w0 * C, v00);
+            VecIO<T, V>::ld(r0 + (long)w1 * C, v01);
+            VecIO<T, V>::ld(r1 + (long)w0 * C, v10);
+            VecIO<T, V>::ld(r1 + (long)w1 * C, v11);
 #pragma unroll
-        for (int r = 0; r < V; ++r) { v00[r] = fmaf(a[r], v00[r], b[r]); v01[r] = fmaf(a[r], v01[r], b[r]); v10[r] = fmaf(a[r], v10[r], b[r]); v11[r] = fmaf(a[r], v11[r], b[r]); }
-        apply_act_vec<V>(v00, act); apply_act_vec<V>(v01, act); apply_act_vec<V>(v10, act); apply_act_vec<V>(v11, act);
+            for (int r = 0; r < V; ++r) { v00[r] = fmaf(a[r], v00[r], b[r]); v01[r] = fmaf(a[r], v01[r], b[r]); v10[r] = fmaf(a[r], v10[r], b[r]); v11[r] = fmaf(a[r], v11[r], b[r]); }
+            apply_act_vec<V>(v00, act); apply_act_vec<V>(v01, act); apply_act_vec<V>(v10, act); apply_act_vec<V>(v11, act);
 #pragma unroll
-        for (int r = 0; r < V; ++r)
-            o[r] = (1.f - lh) * ((1.f - lw) * v00[r] + lw * v01[r]) + lh * ((1.f - lw) * v10[r] + lw * v11[r]);
-        VecIO<T, V>::st(y + (((long)n * OH + oh) * OW + ow) * C + c, o);
+            for (int r = 0; r < V; ++r)
+                o[r] = (1.f - lh) * ((1.f - lw) * v00[r] + lw * v01[r]) + lh * ((1.f - lw) * v10[r] + lw * v11[r]);
+            VecIO<T, V>::st(yr + (long)ow * C, o);
+        }
+    }
     }
 }
 
@@ -440,11 +453,13 @@ extern "C" int sp_bn_apply_upsample2(const void* x, void* y, int32_t n, int32_t 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     Affine aff{gamma, beta, emb, cls};
     const int v = (dtype == SP_BF16 && c % 8 == 0) ? 8 : 4;
-    long blocks = ((long)n * h * w_ * 4 * (c / v) + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    if (dtype == SP_F32) hipLaunchKernelGGL((bn_apply_upsample2_kernel<float, 4>), dim3((unsigned)blocks), dim3(256), 0, s, (const float*)x, (float*)y, n, h, w_, c, mean, invstd, aff, act);
-    else if (v == 8) hipLaunchKernelGGL((bn_apply_upsample2_kernel<bf16, 8>), dim3((unsigned)blocks), dim3(256), 0, s, (const bf16*)x, (bf16*)y, n, h, w_, c, mean, invstd, aff, act);
-    else hipLaunchKernelGGL((bn_apply_upsample2_kernel<bf16, 4>), dim3((unsigned)blocks), dim3(256), 0, s, (const bf16*)x, (bf16*)y, n, h, w_, c, mean, invstd, aff, act);
+    const int groups = c / v, lanes = groups < 256 ? groups : 256, pix_par = 256 / lanes;
+    int bx = (2 * w_ + pix_par * 2 - 1) / (pix_par * 2);            // two output pixels per thread
+    if (bx < 1) bx = 1;
+    const dim3 g(bx, (long)n * 2 * h < 65535 ? n * 2 * h : 65535);
+    if (dtype == SP_F32) hipLaunchKernelGGL((bn_apply_upsample2_kernel<float, 4>), g, dim3(256), 0, s, (const float*)x, (float*)y, n, h, w_, c, mean, invstd, aff, act);
+    else if (v == 8) hipLaunchKernelGGL((bn_apply_upsample2_kernel<bf16, 8>), g, dim3(256), 0, s, (const bf16*)x, (bf16*)y, n, h, w_, c, mean, invstd, aff, act);
+    else hipLaunchKernelGGL((bn_apply_upsample2_kernel<bf16, 4>), g, dim3(256), 0, s, (const bf16*)x, (bf16*)y, n, h, w_, c, mean, invstd, aff, act);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }
