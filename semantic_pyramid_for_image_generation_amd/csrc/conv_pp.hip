@@ -37,9 +37,6 @@
 
 namespace {
 
-#ifndef PP_HOIST
-#define PP_HOIST 1
-#endif
 constexpr int PP_TW = 32;
 constexpr int PP_NUM_CU = 256;                 // MI355X
 constexpr int PP_BIAS_MAX = 1024;              // output channels whose bias fits the LDS copy
@@ -223,7 +220,12 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
         if (bias_in_acc && live) {
             const unsigned ba = bias_addr + (unsigned)co0 * 4u;
             lds_rd128<0>(b4[0], ba); lds_rd128<16>(b4[1], ba); lds_rd128<32>(b4[2], ba); lds_rd128<48>(b4[3], ba);
-            wait_lgkm<0>();                                 // (same straight-line region: see the rule at the hoisted fragment reads)
+            // RULE for every asm LDS read in this file: its lgkmcnt wait follows in the same straight-line region.  The compiler does
+            // not know that the destination registers are written LATER: with a branch or a barrier in between it reused registers of
+            // a read still in flight for address arithmetic (values it considered dead on that path) and the late data overwrote
+            // them - a launch wrong once in a few hundred (round 3: pixel fragments read ahead across a barrier; the variant was
+            // also slower once it waited correctly, and is gone).  tools/check_async_lds.py screens the assembly for this.
+            wait_lgkm<0>();
         }
     };
 
@@ -276,14 +278,9 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
         const int c0_next = item_ends ? 0 : (kc + 1) * KC;
         // FIRST: the first stage of an item - the first MFMA into every accumulator takes the bias registers as its C operand
         // (the item's accumulators are never initialised: 64 moves per wave and item saved)
-        uint4 bf[NB][2];
         auto stage = [&](auto sc, auto fc) {
             constexpr int st = decltype(sc)::value;        // stage inside the chunk = tap column
-            // HOIST: the pixel fragments of stages 1 and 2 are read at the END of the previous stage's MFMA segment, in front of its
-            // barrier: the chunk's halo is complete in LDS since the chunk began (no hazard), the LDS pipe is idle while the barrier
-            // releases, and the LOAD segment of two stages in three shrinks from 20 to 12 reads - below the MFMA segment it pairs with
-            constexpr bool B_HERE = !PP_HOIST || st == 0;
-            constexpr int NREAD = B_HERE ? 12 + 2 * NB : 12;
+            constexpr int NREAD = 12 + 2 * NB;
             constexpr bool FIRST = decltype(fc)::value;
             constexpr int TAP_STRIDE = CO_T * 64;
             constexpr int NH = st == 0 ? G::HPS0 : st == 1 ? G::HPS1 : 0, H0 = st == 0 ? 0 : G::HPS0;   // halo pieces requested in this stage
@@ -291,7 +288,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
             const unsigned ab = a_addr + (unsigned)(g4 * W_BYTES);
             const unsigned bb = b_addr[st] + hb;
             const unsigned bo = HP == 36 ? (bb ^ 32u) : bb; // odd halo rows (pitch 36): swizzle key flipped in bit 1
-            uint4 a[3][4];
+            uint4 a[3][4], bf[NB][2];
             // ================= LOAD segment: every fragment of the stage =================
             const int ws = (g4 + 3) & 3;                    // slot of stage g + 3 = slot of stage g - 1 (its reads ended >= two barriers ago)
             auto piece = [&](auto kc_) {                    // request number k of this stage: halo of the next chunk, then weights of stage g + 3
@@ -351,19 +348,6 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
             });
             if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PP_HOIST && st < 2) {
-                const unsigned bn = b_addr[st + 1] + hb;
-                static_for<2 * NB>([&](auto rc) {
-                    constexpr int h = decltype(rc)::value / 2, hh = decltype(rc)::value % 2;
-                    lds_rd128<h * (HP * 64) + hh * 1024>(bf[h][hh], bn);
-                });
-                // RULE for every asm LDS read in this file: its lgkmcnt(0) follows in the same straight-line region.  The compiler
-                // does not know that the destination registers are written LATER: with a branch or a barrier in between it reused
-                // registers of a read still in flight for address arithmetic (values it considered dead on that path), and the
-                // late data overwrote them - one wrong launch in a few hundred.  Here the wait costs nothing: the wave is about
-                // to idle at the barrier for longer than an LDS round trip.
-                wait_lgkm<0>();
-            }
             stamp(3);
             // (item end, the half that runs behind: its epilogue comes BEFORE this barrier - see below)
             if (two_barriers ? !(st == 2 && item_ends && half_b && !(prio & 128)) : !half_b) __builtin_amdgcn_s_barrier();
