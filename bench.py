@@ -178,10 +178,13 @@ def recorded_traffic(symbols):
         except (OSError, ValueError, KeyError):
             continue
         for symbol in symbols:
-            for kname, rec in kernels.items():
-                if symbol in kname:
-                    return rec["hbm_bytes_per_launch"], {"file": "profiles/" + name, "sha256_16": hashlib.sha256(raw).hexdigest()[:16],
-                                                         "kernel": kname[:96], "launches_profiled": rec.get("launches_profiled")}
+            # every instantiation of the kernel that serves the dominant launches (e.g. its two epilogue forms), launch-weighted
+            hits = [(kname, rec) for kname, rec in kernels.items() if symbol in kname]
+            if hits:
+                n = sum(rec.get("launches_profiled") or 1 for _, rec in hits)
+                avg = sum(rec["hbm_bytes_per_launch"] * (rec.get("launches_profiled") or 1) for _, rec in hits) / n
+                return int(avg), {"file": "profiles/" + name, "sha256_16": hashlib.sha256(raw).hexdigest()[:16],
+                                  "kernel": " + ".join(k[:96] for k, _ in hits), "launches_profiled": n}
     return None, None
 
 

@@ -211,8 +211,9 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
 
     const bool bias_in_acc = !G::F8 && p.bias != nullptr && !up && cotiles * CO_T <= PP_BIAS_MAX;   // (SP_F8: the bias follows the scale)
     f32x4_t acc[4][NFR];
-    // accumulators of an item start at its bias, held in 16 registers that the item's first stage feeds to its MFMAs as the C
-    // operand; the LDS reads for the NEXT item are issued (and waited for) at the end of the epilogue
+    // accumulators of an item start at its bias (LDS copy: no global load whose wait would drain the DMA queue).  Measured and not
+    // kept: the first stage of an item taking the bias registers as the MFMA C operand instead of 64 moves (a fourth copy of the
+    // stage code: step 17.63 vs 17.59 ms)
     uint4 b4[4];
     auto bias_fetch = [&](bool live, int co0) {
 #pragma unroll
@@ -243,13 +244,17 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     bias_fetch(true, cur.co_i * CO_T);
-    // A/B switch (SP_TUNE_CONV_PP_PRIO bit 8): ONE barrier per stage - the leading half synchronises only behind its MFMA
-    // segment, the other half only behind its LOAD segment, an interval is  L(g) M(g)  for one half and  M(g-1) L(g)  for the
-    // other; every hazard still has a barrier in between and an s_barrier release (~220 cycles) is paid once per stage.  Measured:
-    // the half that multiplies first in an interval loses the matrix pipe to its partner's tail (its MFMA segment 780 -> 1 050
-    // cycles); full step 18.19 vs 18.01 ms with two barriers.  Default: two.
-    const bool two_barriers = (prio & 256) == 0;
-    if (half_b && two_barriers) __builtin_amdgcn_s_barrier();   // (two barriers: from here on this half runs one segment behind)
+    auto acc_from_bias = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NFR; ++j) acc[i][j] = __builtin_bit_cast(f32x4_t, b4[i]);
+    };
+    acc_from_bias();
+    // Measured and not kept (profiles/README.md): ONE barrier per stage (the leading half synchronises only behind its MFMA segment,
+    // the other only behind its LOAD segment; every hazard still has a barrier in between) - the half that multiplies first in an
+    // interval loses the matrix pipe to its partner's tail (MFMA segment 780 -> 1 050 cycles), full step 18.19 vs 18.01 ms.
+    if (half_b) __builtin_amdgcn_s_barrier();               // from here on this half runs one segment behind
 
     if ((prio & 2) && half_b) __builtin_amdgcn_s_setprio(1);
     // TIMING build (diagnostics, SP_TUNE_CONV_PP_PRIO bit 2): cycles per wave in [0] LOAD segment up to the counted wait (fragment
@@ -276,12 +281,9 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
         if constexpr (TIMING) stamp_on = kc != 0 && !item_ends;
         const unsigned hb = (unsigned)((gc & 1) * HALO_BUF);
         const int c0_next = item_ends ? 0 : (kc + 1) * KC;
-        // FIRST: the first stage of an item - the first MFMA into every accumulator takes the bias registers as its C operand
-        // (the item's accumulators are never initialised: 64 moves per wave and item saved)
-        auto stage = [&](auto sc, auto fc) {
+        auto stage = [&](auto sc) {
             constexpr int st = decltype(sc)::value;        // stage inside the chunk = tap column
             constexpr int NREAD = 12 + 2 * NB;
-            constexpr bool FIRST = decltype(fc)::value;
             constexpr int TAP_STRIDE = CO_T * 64;
             constexpr int NH = st == 0 ? G::HPS0 : st == 1 ? G::HPS1 : 0, H0 = st == 0 ? 0 : G::HPS0;   // halo pieces requested in this stage
             constexpr int NPIECE = NH + W_PER;
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
             stamp(1);
             wait_lgkm<0>();                                 // every LDS read of this wave has returned before it signals
             stamp(7);
-            if (two_barriers || half_b) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             stamp(2);
             // ================= MFMA segment, with this stage's requests behind its MFMA groups =================
@@ -338,11 +340,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int hh = 0; hh < 2; ++hh) {
-                            f32x4_t c = (FIRST && dr == 0) ? __builtin_bit_cast(f32x4_t, b4[i]) : acc[i][rr * 2 + hh];
-                            Mma<T>::run(a[dr][i], bf[h][hh], c);
-                            acc[i][rr * 2 + hh] = c;
-                        }
+                        for (int hh = 0; hh < 2; ++hh) Mma<T>::run(a[dr][i], bf[h][hh], acc[i][rr * 2 + hh]);
                     if constexpr (!DMA_IN_L) piece(std::integral_constant<int, pp_group_index(h, dr, RW)>{});   // behind MFMA group k: request k
                 }
             });
@@ -350,15 +348,14 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
             __builtin_amdgcn_sched_barrier(0);
             stamp(3);
             // (item end, the half that runs behind: its epilogue comes BEFORE this barrier - see below)
-            if (two_barriers ? !(st == 2 && item_ends && half_b && !(prio & 128)) : !half_b) __builtin_amdgcn_s_barrier();
+            if (!(st == 2 && item_ends && half_b)) __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             stamp(4);
             g4 = (g4 + 1) & 3;
         };
-        if (kc == 0) stage(std::integral_constant<int, 0>{}, std::true_type{});
-        else stage(std::integral_constant<int, 0>{}, std::false_type{});
-        stage(std::integral_constant<int, 1>{}, std::false_type{});
-        stage(std::integral_constant<int, 2>{}, std::false_type{});
+        stage(std::integral_constant<int, 0>{});
+        stage(std::integral_constant<int, 1>{});
+        stage(std::integral_constant<int, 2>{});
         if (item_ends) {
             // BOTH epilogues in one barrier interval.  After its last MFMA segment the leading half passes the barrier, runs its
             // epilogue and the next item's first LOAD segment; the other half is in its last MFMA segment meanwhile and would then
@@ -559,13 +556,14 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
             nxt = advance(nxt);
             stamp(5);
             bias_fetch(more_chunks, cur.co_i * CO_T);       // (after the epilogue's own reads of the bias / scale tables)
+            acc_from_bias();
             stamp(8);
-            if (half_b && two_barriers && !(prio & 128)) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+            if (half_b) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
         } else {
             ++kc;
         }
     }
-    if (!half_b && two_barriers) __builtin_amdgcn_s_barrier();  // the barrier the other half passes after its last MFMA segment
+    if (!half_b) __builtin_amdgcn_s_barrier();              // the barrier the other half passes after its last MFMA segment
     if constexpr (G::F8) {
         // one atomic per BLOCK on the running maximum (per item and wave they serialise on one L2 word: 10 K atomics = 100+ us)
         if (p.y8_amax != nullptr) {
@@ -628,8 +626,8 @@ int sp_conv_pp_launch(const sp_conv_params& p, int th, hipStream_t s) {
     if (p.dtype != SP_BF16 || p.ksize != 3 || p.h % th != 0 || p.w_ % PP_TW != 0) return 1;
     const long esz = 2;
     if ((long)p.n * p.h * p.w_ * p.cin_p * esz >= (1L << 30) || (long)p.cout * 9 * p.cin_p * esz >= (1L << 30)) return 1;
-    // SP_TUNE_CONV_PP_PRIO (diagnostics / A-B): bit 2 = the TIMING build, bit 4 = the general epilogue everywhere, bit 7 = the two
-    // halves' epilogues in separate barrier intervals (the round-3 mid-state)
+    // SP_TUNE_CONV_PP_PRIO (diagnostics / A-B): bit 2 = the TIMING build (bit 9 with it: stamps of mid-item chunks only),
+    // bit 4 = the general epilogue everywhere
     const int prio = sp_tune(SP_TUNE_CONV_PP_PRIO, 1);
     const bool fast = !(prio & 16) && p.pool2 == 0 && (p.cout & 15) == 0 && (p.ldy & 7) == 0 && p.act != SP_ACT_TANH;
     if (th == 16 && p.cout <= 64)                          // 64 co x 16x32 px
