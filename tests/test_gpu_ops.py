@@ -182,6 +182,72 @@ def test_conv_epilogue_act_and_residuals(dtype):
     close(m.weight_orig.grad, S["c.weight_orig"].grad, 2 * tol, "dW")
 
 
+PP_EPILOGUE_CASES = [  # (n, cin, cout, hw, act, residuals, mask, pool2, input-upsampled, bias)
+    (2, 128, 128, 64, 1, 0, False, 0, False, True), (3, 64, 128, 64, 0, 2, False, 0, False, True), (3, 136, 128, 64, 1, 0, False, 0, False, True),
+    (2, 128, 128, 64, 0, 0, True, 0, False, False), (2, 128, 256, 64, 0, 2, False, 1, False, True), (2, 64, 128, 64, 2, 0, False, 2, False, True),
+    (2, 256, 128, 64, 0, 0, True, 0, True, False), (5, 32, 192, 32, 3, 0, False, 0, False, True), (2, 64, 72, 32, 1, 0, False, 0, False, True),
+    (20, 256, 512, 32, 1, 1, False, 0, False, True),
+    # Cout <= 64: the eight-row-pair-wave form
+    (2, 64, 64, 64, 1, 0, False, 0, False, True), (3, 128, 64, 128, 0, 2, False, 0, False, True), (2, 72, 64, 32, 0, 0, True, 0, False, False),
+    (2, 64, 64, 64, 2, 0, False, 2, False, True), (2, 64, 64, 64, 0, 1, False, 1, False, True), (3, 32, 40, 32, 1, 0, False, 0, False, True),
+]
+
+
+@pytest.mark.parametrize("case", PP_EPILOGUE_CASES)
+def test_conv3x3_pingpong_epilogue_variants_bf16(case):
+    """The ping-pong 3x3 kernel (conv_pp.hip: both co-tile forms, the one-pass-per-operand epilogue and the general one) over its
+    epilogue variants - bias, LeakyReLU / ReLU / tanh, one and two residuals, the activation-gradient mask, 2x2 average / max
+    pooling, the pooled-gradient input - at shapes that reach it (W % 32 == 0): (a) against fp32 arithmetic on the same bf16
+    operands, (b) BIT-IDENTICAL to the round-2 kernels (SP_TUNE_CONV_PP = 0), three launches each into a dirty output (the
+    block is persistent: the second item of a block must not depend on what the first left behind)."""
+    n, cin, cout, hw, act, res, mask, pool2, up, bias = case
+    dt = torch.bfloat16
+    g = torch.Generator(device="cuda").manual_seed(5)
+    hin = hw // 2 if up else hw
+    ho = hw // 2 if pool2 else hw
+    x = ops.nhwc_empty(n, cin, hin, hin, dt, "cuda").normal_(generator=g)
+    w = (torch.randn(cout, 3, 3, cin, device="cuda", generator=g) * 0.05).to(dt)          # packed forward layout [co][tap][ci]
+    b = torch.randn(cout, device="cuda", generator=g) if bias else None
+    mk = lambda: ops.nhwc_empty(n, cout, ho, ho, dt, "cuda").normal_(generator=g)
+    r1 = mk() if res >= 1 else None
+    r2 = mk() if res >= 2 else None
+    ms = mk() if mask else None
+
+    def launch(y):
+        ops._conv_launch(x, w.data_ptr(), b, y, r1, r2, ms, 0.2, n, hw, hw, cin, cout, cout, 3, act, dt, pool2, up)
+
+    # (a) fp32 reference on the bf16 operands
+    xin = x.float()
+    if up:                                                     # the input stands for the gradient of a 2x2 average pooling
+        xin = 0.25 * F.interpolate(xin, scale_factor=2, mode="nearest")
+    ref = F.conv2d(xin, w.float().permute(0, 3, 1, 2), b, padding=1)
+    if pool2 == 1:
+        ref = F.avg_pool2d(ref, 2)
+    elif pool2 == 2:
+        ref = F.max_pool2d(ref, 2)
+    if ms is not None:
+        ref = ref * torch.where(ms.float() > 0, 1.0, 0.2)
+    if r1 is not None:
+        ref = ref + r1.float()
+    if r2 is not None:
+        ref = ref + r2.float()
+    ref = {0: lambda t: t, 1: lambda t: F.leaky_relu(t, 0.2), 2: F.relu, 3: torch.tanh}[act](ref)
+    y = ops.nhwc_empty(n, cout, ho, ho, dt, "cuda").fill_(-7.0)
+    launch(y)
+    close(y, ref.cpu(), 8e-3, "ping-pong kernel vs fp32")
+    # (b) bit-identical to the round-2 kernels
+    ops.set_tuning(21, 0)
+    try:
+        y0 = ops.nhwc_empty(n, cout, ho, ho, dt, "cuda").fill_(3.0)
+        launch(y0)
+    finally:
+        ops.set_tuning(21, -1)
+    for rep in range(3):
+        y1 = ops.nhwc_empty(n, cout, ho, ho, dt, "cuda").fill_(-7.0)
+        launch(y1)
+        assert torch.equal(y0, y1), (case, rep, int((y0 != y1).sum()))
+
+
 @pytest.mark.parametrize("case", [(128, 256, 3, 2, 8, 8), (520, 128, 3, 1, 8, 8), (64, 72, 3, 5, 8, 8), (512, 512, 3, 20, 8, 8), (72, 64, 3, 3, 16, 16)])
 def test_wgrad_row_walker_narrow_maps_bf16(case):
     """Row-walking weight-gradient kernel on narrow maps (several images side by side in one 32-pixel strip): 8 x 8 maps are off
