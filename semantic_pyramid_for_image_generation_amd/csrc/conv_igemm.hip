@@ -1545,6 +1545,15 @@ int dispatch(const sp_conv_params& p, hipStream_t s) {
         if (fits30 && (tall_mode == 3 || (tall_mode == 1 && short_env))) return launch_tall<T, 2, 8>(p, s);
         return launch_halo<T, 128, 3>(p, s);
     }
+    // 16-wide maps, Cout > 64, bf16: the ping-pong kernel on 16 x 16-pixel tiles (conv_pp.hip; SP_TUNE_CONV_PP = 0 or 2 keeps the
+    // LDS-DMA igemm below)
+    if (sizeof(T) == 2 && p.ksize == 3 && p.w_ == 16 && p.cout > 64) {
+        const int ppm = sp_tune(SP_TUNE_CONV_PP, 1);
+        if (ppm == 1 || ppm == 3) {
+            const int rc = sp_conv_pp_launch(p, 1616, s);
+            if (rc != 1) return rc;
+        }
+    }
     // LDS-DMA kernel: measured faster for the small-spatial 3x3 layers (latency-bound), slower for 1x1 (profiles/README.md);
     // SP_IGEMM_DMA=2 forces it everywhere, 0 disables it
     const int dma_mode = sp_tune(SP_TUNE_IGEMM_DMA, 1);

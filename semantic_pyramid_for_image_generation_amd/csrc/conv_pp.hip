@@ -37,17 +37,19 @@
 
 namespace {
 
-constexpr int PP_TW = 32;
+constexpr int PP_TW_WIDE = 32;
 constexpr int PP_NUM_CU = 256;                 // MI355X
 constexpr int PP_BIAS_MAX = 1024;              // output channels whose bias fits the LDS copy
 
-template <typename T, int WCO>
+template <typename T, int WCO, int FW = 2>
 struct PPGeom {
     static constexpr int E = 16 / (int)sizeof(T), KC = 4 * E;
     // WCO = 2: 128 co x (8 x 32) px per block, waves = 2 (co halves) x 4 (row pairs);  WCO = 1 (Cout <= 64): 64 co x (16 x 32) px,
     // waves = 8 row pairs.  Either way a wave owns 64 co x (2 rows x 32 columns): the same fragment / MFMA program.
-    static constexpr int CO_T = 64 * WCO, WPX = 8 / WCO, RW = 2, TH = WPX * RW, NB = RW + 2, NFR = RW * 2, HR = TH + 2;
-    static constexpr int HP = 40;                                     // halo pitch in pixels
+    // FW = 16-pixel fragments per tile row: 2 = 32-pixel-wide tiles (a wave: 2 rows x 32 columns), 1 = 16-pixel-wide tiles for maps
+    // 16 wide (a wave: 4 rows x 16 columns; 128 co x 16 x 16 px per block = one whole 16 x 16 image).  Same 48 MFMAs per stage.
+    static constexpr int CO_T = 64 * WCO, WPX = 8 / WCO, RW = 4 / FW, TH = WPX * RW, NB = RW + 2, NFR = RW * FW, HR = TH + 2, TW = 16 * FW;
+    static constexpr int HP = FW == 2 ? 40 : 20;                      // halo pitch in pixels (20: odd rows flip swizzle-key bit 1, like 36)
     static constexpr int HALO_INSTR = (HR * HP * 64 + 1023) / 1024;   // wave-instructions of 1 KB per halo chunk
     static constexpr int HALO_BUF = HALO_INSTR * 1024;
     static constexpr int HPW = (HALO_INSTR + 7) / 8;                  // ... per wave (round robin; the tail ones are dummies)
@@ -75,9 +77,11 @@ constexpr int pp_group_index(int h, int dr, int rw) {
 // tanh.  The general epilogue (per-lane `wide` test, 4-channel and scalar tails, pooling, an inlined tanh per value and call site) is
 // 18 K instructions in ~1 100 basic blocks around a 1.7 K-instruction loop; measured with compile-time assumptions in its place
 // (scratch: -DPP_ASSUME_SIMPLE), a launch of 128->128 @128^2 drops from 170 K to 148 K cycles per block, 64->128 from 111 K to 92 K.
-template <typename T, int WCO, int PRIO, bool TIMING = false, bool DMA_IN_L = true, bool FAST = false>
+template <typename T, int WCO, int PRIO, bool TIMING = false, bool DMA_IN_L = true, bool FAST = false, int FW = 2>
 __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int cotiles, int total, int prio) {
-    using G = PPGeom<T, WCO>;
+    using G = PPGeom<T, WCO, FW>;
+    static_assert(FW == 2 || (sizeof(T) == 2 && FAST), "16-wide tiles: bf16, FAST epilogue (no pooling)");
+    constexpr int PP_TW = G::TW;
     static_assert(!FAST || sizeof(T) == 2, "FAST epilogue: bf16");
     constexpr int E = G::E, KC = G::KC, CO_T = G::CO_T, WPX = G::WPX, RW = G::RW, NB = G::NB, NFR = G::NFR, HR = G::HR, HP = G::HP, TH = G::TH;
     constexpr int HALO_INSTR = G::HALO_INSTR, HALO_BUF = G::HALO_BUF, HPW = G::HPW, W_BYTES = G::W_BYTES, W_PER = G::W_PER, W_INSTR = G::W_INSTR;
@@ -283,14 +287,14 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
         const int c0_next = item_ends ? 0 : (kc + 1) * KC;
         auto stage = [&](auto sc) {
             constexpr int st = decltype(sc)::value;        // stage inside the chunk = tap column
-            constexpr int NREAD = 12 + 2 * NB;
+            constexpr int NREAD = 12 + FW * NB;
             constexpr int TAP_STRIDE = CO_T * 64;
             constexpr int NH = st == 0 ? G::HPS0 : st == 1 ? G::HPS1 : 0, H0 = st == 0 ? 0 : G::HPS0;   // halo pieces requested in this stage
             constexpr int NPIECE = NH + W_PER;
             const unsigned ab = a_addr + (unsigned)(g4 * W_BYTES);
             const unsigned bb = b_addr[st] + hb;
-            const unsigned bo = HP == 36 ? (bb ^ 32u) : bb; // odd halo rows (pitch 36): swizzle key flipped in bit 1
-            uint4 a[3][4], bf[NB][2];
+            const unsigned bo = (HP == 36 || HP == 20) ? (bb ^ 32u) : bb; // odd halo rows (pitch 36 / 20): swizzle key flipped in bit 1
+            uint4 a[3][4], bf[NB][FW];
             // ================= LOAD segment: every fragment of the stage =================
             const int ws = (g4 + 3) & 3;                    // slot of stage g + 3 = slot of stage g - 1 (its reads ended >= two barriers ago)
             auto piece = [&](auto kc_) {                    // request number k of this stage: halo of the next chunk, then weights of stage g + 3
@@ -310,7 +314,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
                     if constexpr (r < 12) {
                         lds_rd128<(r / 4) * TAP_STRIDE + (r % 4) * 256>(a[r / 4][r % 4], ab);
                     } else if constexpr (r < NREAD) {
-                        constexpr int h = (r - 12) / 2, hh = (r - 12) % 2;
+                        constexpr int h = (r - 12) / FW, hh = (r - 12) % FW;
                         lds_rd128<h * (HP * 64) + hh * 1024>(bf[h][hh], (h & 1) ? bo : bb);
                     }
                 });
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int hh = 0; hh < 2; ++hh) Mma<T>::run(a[dr][i], bf[h][hh], acc[i][rr * 2 + hh]);
+                        for (int hh = 0; hh < FW; ++hh) Mma<T>::run(a[dr][i], bf[h][hh], acc[i][rr * FW + hh]);
                     if constexpr (!DMA_IN_L) piece(std::integral_constant<int, pp_group_index(h, dr, RW)>{});   // behind MFMA group k: request k
                 }
             });
@@ -379,7 +383,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
                 // residuals / activation, its own load -> wait) cost ~640 cycles per fragment, 5x its VALU work
                 if (wide) {
                     const long off0 = pix0 * p.ldy + co_b;
-                    auto foff = [&](int j) { return off0 + ((long)(j >> 1) * W + (j & 1) * 16) * p.ldy; };
+                    auto foff = [&](int j) { return off0 + ((long)(j / FW) * W + (j % FW) * 16) * p.ldy; };
                     if (!bias_in_acc && p.bias != nullptr) {
                         float t[16];
                         Wide16<float>::ld(p.bias + co_b, t);
@@ -592,20 +596,20 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
     }
 }
 
-template <typename T, int WCO, int PRIO, bool TIMING = false, bool DMA_IN_L = true, bool FAST = false>
+template <typename T, int WCO, int PRIO, bool TIMING = false, bool DMA_IN_L = true, bool FAST = false, int FW = 2>
 int launch_pp(const sp_conv_params& p, int prio, hipStream_t s) {
-    using G = PPGeom<T, WCO>;
+    using G = PPGeom<T, WCO, FW>;
     constexpr int TH = G::TH;
     static_assert(G::LDS <= 163840, "LDS budget");
     static bool attr_set = false;
-    auto kern = conv3x3_pp_kernel<T, WCO, PRIO, TIMING, DMA_IN_L, FAST>;
+    auto kern = conv3x3_pp_kernel<T, WCO, PRIO, TIMING, DMA_IN_L, FAST, FW>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
         if (e != hipSuccess) { sp_set_error("hipFuncSetAttribute(LDS=%d) failed: %s", G::LDS, hipGetErrorString(e)); return SP_ERR_LAUNCH; }
         attr_set = true;
     }
     const int cotiles = (p.cout + G::CO_T - 1) / G::CO_T;
-    const int total = p.n * (p.h / TH) * (p.w_ / PP_TW) * cotiles;
+    const int total = p.n * (p.h / TH) * (p.w_ / G::TW) * cotiles;
     int grid = total < PP_NUM_CU ? total : PP_NUM_CU;       // persistent: one block per CU
     if (grid >= 8) grid -= grid % 8;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), G::LDS, s, p, cotiles, total, prio);
@@ -619,12 +623,24 @@ int launch_pp(const sp_conv_params& p, int prio, hipStream_t s) {
 // Returns 1 if the shape is not covered (the caller then keeps its own kernel).
 int sp_conv_pp_launch(const sp_conv_params& p, int th, hipStream_t s) {
     if (p.dtype == SP_F8) {
-        if (p.ksize != 3 || p.cout <= 64 || p.h % 8 != 0 || p.w_ % PP_TW != 0 || (long)p.n * p.h * p.w_ * p.cin_p >= (1L << 30) ||
+        if (p.ksize != 3 || p.cout <= 64 || p.h % 8 != 0 || p.w_ % PP_TW_WIDE != 0 || (long)p.n * p.h * p.w_ * p.cin_p >= (1L << 30) ||
             (long)p.cout * 9 * p.cin_p >= (1L << 30) || (p.cout + 127) / 128 * 128 > PP_BIAS_MAX) return 1;
         return launch_pp<f8, 2, 1>(p, 1, s);
     }
-    if (p.dtype != SP_BF16 || p.ksize != 3 || p.h % th != 0 || p.w_ % PP_TW != 0) return 1;
+    if (p.dtype != SP_BF16 || p.ksize != 3) return 1;
     const long esz = 2;
+    if (th == 1616) {
+        // maps 16 wide (th code 1616): 128 co x 16 x 16 px tiles - one whole image of the 16 x 16 layers per block.  Few items (80 for
+        // 512 -> 512 at batch 20), but each runs the ping-pong pipeline on a 128 x 256 tile instead of sixteen 64 x 64 tiles
+        // that re-read their operands from L2 (the LDS-DMA igemm these layers used): 512 -> 512: 53.4 -> 44.6 us, 520 -> 512: 70.8 ->
+        // 46.8, 256 -> 512: 29.0 -> 25.2; with 40 items (Cout 256) it is no faster - those stay on the igemm.  Split-K over 2-4 K
+        // ranges (fp32 partial tiles + the finalize pass) was built and measured: 60 us - a 128 x 256 fp32 tile per 12 stages is
+        // more store-path time than the extra parallelism buys
+        if (p.w_ != 16 || p.h % 16 != 0 || (long)p.n * (p.h / 16) * ((p.cout + 127) / 128) < 64 || p.pool2 != 0 || (p.cout & 15) != 0 || (p.ldy & 7) != 0 || p.act == SP_ACT_TANH) return 1;
+        if ((long)p.n * p.h * p.w_ * p.cin_p * esz >= (1L << 30) || (long)p.cout * 9 * p.cin_p * esz >= (1L << 30)) return 1;
+        return launch_pp<bf16, 2, 1, false, true, true, 1>(p, 1, s);
+    }
+    if (p.h % th != 0 || p.w_ % PP_TW_WIDE != 0) return 1;
     if ((long)p.n * p.h * p.w_ * p.cin_p * esz >= (1L << 30) || (long)p.cout * 9 * p.cin_p * esz >= (1L << 30)) return 1;
     // SP_TUNE_CONV_PP_PRIO (diagnostics / A-B): bit 2 = the TIMING build (bit 9 with it: stamps of mid-item chunks only),
     // bit 4 = the general epilogue everywhere

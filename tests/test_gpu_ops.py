@@ -248,6 +248,39 @@ def test_conv3x3_pingpong_epilogue_variants_bf16(case):
         assert torch.equal(y0, y1), (case, rep, int((y0 != y1).sum()))
 
 
+@pytest.mark.parametrize("case", [(20, 128, 512, 1, 0, False, True), (16, 520, 512, 0, 2, False, True), (32, 72, 256, 2, 0, True, False),
+                                  (9, 64, 1024, 1, 1, False, True)])
+def test_conv3x3_pingpong_16_wide_tiles_bf16(case):
+    """16 x 16 maps with enough (image, 128-channel tile) items: the ping-pong kernel on 128 co x 16 x 16 px tiles (conv_pp.hip,
+    FW = 1: a wave owns 4 rows x 16 columns, halo pitch 20) against fp32 arithmetic on the same bf16 operands, and three launches
+    into dirty outputs that must agree bit for bit."""
+    n, cin, cout, act, res, mask, bias = case
+    dt = torch.bfloat16
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = ops.nhwc_empty(n, cin, 16, 16, dt, "cuda").normal_(generator=g)
+    w = (torch.randn(cout, 3, 3, cin, device="cuda", generator=g) * 0.05).to(dt)
+    b = torch.randn(cout, device="cuda", generator=g) if bias else None
+    mk = lambda: ops.nhwc_empty(n, cout, 16, 16, dt, "cuda").normal_(generator=g)
+    r1 = mk() if res >= 1 else None
+    r2 = mk() if res >= 2 else None
+    ms = mk() if mask else None
+    ref = F.conv2d(x.float(), w.float().permute(0, 3, 1, 2), b, padding=1)
+    if ms is not None:
+        ref = ref * torch.where(ms.float() > 0, 1.0, 0.2)
+    if r1 is not None:
+        ref = ref + r1.float()
+    if r2 is not None:
+        ref = ref + r2.float()
+    ref = {0: lambda t: t, 1: lambda t: F.leaky_relu(t, 0.2), 2: F.relu}[act](ref)
+    ys = []
+    for rep in range(3):
+        y = ops.nhwc_empty(n, cout, 16, 16, dt, "cuda").fill_(-7.0)
+        ops._conv_launch(x, w.data_ptr(), b, y, r1, r2, ms, 0.2, n, 16, 16, cin, cout, cout, 3, act, dt, 0, False)
+        ys.append(y)
+    close(ys[0], ref.cpu(), 8e-3, "16-wide ping-pong tiles vs fp32")
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
+
+
 @pytest.mark.parametrize("case", [(128, 256, 3, 2, 8, 8), (520, 128, 3, 1, 8, 8), (64, 72, 3, 5, 8, 8), (512, 512, 3, 20, 8, 8), (72, 64, 3, 3, 16, 16)])
 def test_wgrad_row_walker_narrow_maps_bf16(case):
     """Row-walking weight-gradient kernel on narrow maps (several images side by side in one 32-pixel strip): 8 x 8 maps are off
