@@ -49,7 +49,7 @@ def timeit(fn, iters=20):
     for _ in range(iters): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
-B = 20; tot = [0.0, 0.0]
+B = 20; tot = [0.0, 0.0, 0.0]
 for cin, cout, hw in [(64, 64, 256), (128, 128, 128), (256, 256, 64), (512, 512, 32), (64, 128, 128), (128, 256, 64), (256, 512, 32), (256, 256, 32), (264, 256, 32), (72, 64, 128), (136, 128, 64)]:
     x = ops.nhwc_empty(B, cin, hw, hw, dt, 'cuda'); x.normal_()
     cp = (cout + 7) // 8 * 8
@@ -61,9 +61,9 @@ for cin, cout, hw in [(64, 64, 256), (128, 128, 128), (256, 256, 64), (512, 512,
                             ops.ptr(ws) if wsf else None, wsf, B, hw, hw, cin, cout, cp, 3, L.SP_BF16, ops.stream()))
     flops = 2.0 * B * hw * hw * cin * cout * 9
     res = []
-    for pp in (0, 1):
+    for k, pp in enumerate((0, 2, 1)):
         lib.sp_set_tuning(23, pp)
-        t = min(timeit(call) for _ in range(3)); res.append(t); tot[pp] += t
+        t = min(timeit(call) for _ in range(3)); res.append(t); tot[k] += t
     lib.sp_set_tuning(23, -1)
-    print("%4d->%4d @%3d  old %7.1f us %6.0f TF | pp %7.1f us %6.0f TF" % (cin, cout, hw, res[0] * 1e3, flops / res[0] / 1e9, res[1] * 1e3, flops / res[1] / 1e9), flush=True)
-print("sum old %.3f ms pp %.3f ms" % tuple(tot))
+    print("%4d->%4d @%3d  row walker %7.1f us %6.0f TF | pp (alternating steps) %7.1f us %6.0f TF | pp3 (rows in registers) %7.1f us %6.0f TF" % (cin, cout, hw, res[0] * 1e3, flops / res[0] / 1e9, res[1] * 1e3, flops / res[1] / 1e9, res[2] * 1e3, flops / res[2] / 1e9), flush=True)
+print("sum row walker %.3f ms pp %.3f ms pp3 %.3f ms" % tuple(tot))

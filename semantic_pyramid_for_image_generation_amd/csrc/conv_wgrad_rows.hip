@@ -652,6 +652,292 @@ __global__ __launch_bounds__(512) void conv_wgrad_pp_kernel(WrArgs a, int rows_p
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The same walk with the X rows carried in REGISTERS.  In the kernel above the halves take alternate row steps, so a wave
+// reads the fragments of all three X rows of its step from LDS: 8 + 18 transposed reads per 36 MFMAs - the LOAD segment
+// (~830 cycles of LDS pipe for four waves) is longer than the MFMA segment it pairs with (576).  Here each half walks its OWN
+// contiguous half of the block's row range (own request cursor, own 4-slot ring: the same LDS and the same L2 traffic): two of
+// the three X rows of a step are the previous step's, still in registers in fragment form, and a step reads only the row that is
+// new - 8 + 6 reads per 36 MFMAs.  Three register sets rotate their roles (tap row 0 / 1 / 2), so the step loop is unrolled by
+// three with the set of every read and of every MFMA operand fixed at compile time (sets pinned to v196.., as above).
+// A ring slot is read in exactly one step (fragments of both operands), so a request distance of three steps needs four slots.
+// ------------------------------------------------------------------------------------------------------------------------------
+#define WP3_BREAD(LO0, HI0, LO1, HI1, LO2, HI2, SET)                                                                               \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:0" : "={v[" LO0 "]}"(Blo[SET][0]) : "v"(bbase + b_off[0]));                     \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "={v[" HI0 "]}"(Bhi[SET][0]) : "v"(bbase + b_off[0]));                  \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:0" : "={v[" LO1 "]}"(Blo[SET][1]) : "v"(bbase + b_off[1]));                     \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "={v[" HI1 "]}"(Bhi[SET][1]) : "v"(bbase + b_off[1]));                  \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:0" : "={v[" LO2 "]}"(Blo[SET][2]) : "v"(bbase + b_off[2]));                     \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "={v[" HI2 "]}"(Bhi[SET][2]) : "v"(bbase + b_off[2]));
+
+constexpr int WP3_NS = 4, WP3_D = 3;                       // ring slots per half, request distance in (own) steps
+__global__ __launch_bounds__(512) void conv_wgrad_pp3_kernel(WrArgs a, int rows_per_block, int rows_total) {
+    extern __shared__ __attribute__((aligned(16))) char wp_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave >> 2, wq = wave & 3;
+    const int H = a.H, W = a.W, CIN = a.CIN;
+    const int co0 = (blockIdx.y / a.ci_tiles) * 64, ci0 = (blockIdx.y % a.ci_tiles) * 64;
+    const int strips = W / 32;
+    const int B0 = (int)blockIdx.x * rows_per_block;
+    const int B1 = B0 + rows_per_block < rows_total ? B0 + rows_per_block : rows_total;
+    if (B0 >= B1) return;
+    // this half's rows [R0, R1): the first half takes the extra row of an odd range
+    const int Bm = B0 + (B1 - B0 + 1) / 2;
+    const int R0 = half ? Bm : B0, R1 = half ? B1 : Bm;
+    auto steps_of = [&](int r0, int r1) { return r1 > r0 ? (r1 - r0) + 2 * ((r1 - 1) / H - r0 / H + 1) : 0; };   // + two halo steps per column
+    const int S = steps_of(R0, R1);
+    const int S_other = half ? steps_of(B0, Bm) : steps_of(Bm, B1);
+    const int S_max = S > S_other ? S : S_other;
+    const int S_pad = (S_max + 2) / 3 * 3;
+    const unsigned lds_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)wp_smem);
+    constexpr unsigned OOB = 0x80000000u;
+    auto uniform_ptr = [](const void* q) {
+        const unsigned long long v = (unsigned long long)(uintptr_t)q;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return (void*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+    };
+    const int up = a.dy_up2 ? 1 : 0;
+    const int HY = H >> up, WY = W >> up;
+    const float oscale = up ? 0.25f : 1.f;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.x), 0, __builtin_amdgcn_readfirstlane(a.N * H * W * CIN * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.dy), 0, __builtin_amdgcn_readfirstlane(a.N * HY * WY * a.LD_DY * 2), 0x00020000);
+
+    const int dpx = lane >> 3;
+    const int dls = ((((lane & 7) >> 1) ^ ((dpx >> 1) & 3)) << 1) | (lane & 1);
+    const bool x_ch_ok = ci0 + dls * 8 < CIN;
+    const bool y_ch_ok = co0 + dls * 8 < a.LD_DY;
+    const unsigned x_lane = (unsigned)((ci0 + dls * 8) * 2), y_lane = (unsigned)((co0 + dls * 8) * 2);
+
+    struct Cursor { int n, x0, y, phase; unsigned xoff, yoff; };
+    const unsigned x_pitch = (unsigned)(W * CIN * 2), y_pitch = (unsigned)(WY * a.LD_DY * 2);
+    auto rebase = [&](Cursor& c) {
+        c.xoff = (unsigned)(((c.n * H + c.y) * W + c.x0 - 1) * CIN * 2);
+        c.yoff = (unsigned)(((c.n * HY) * WY + (c.x0 >> up)) * a.LD_DY * 2);
+    };
+    auto advance = [&](Cursor& c) {
+        if (c.phase < 2) { ++c.phase; return; }
+        c.xoff += x_pitch;
+        if (++c.y == H) {
+            c.y = 0; c.phase = 0;
+            c.x0 += 32;
+            if (c.x0 == W) { c.x0 = 0; ++c.n; }
+            rebase(c);
+        }
+    };
+    const int px_a = wq * 8 + dpx, px_b = 32 + dpx;
+    const unsigned xl_a = (unsigned)(px_a * CIN * 2) + x_lane, xl_b = (unsigned)(px_b * CIN * 2) + x_lane;
+    const unsigned yl = (unsigned)((((wq * 8 + dpx) >> up) * a.LD_DY) * 2) + y_lane;
+    const unsigned ring_x = (unsigned)(half * WP3_NS * WR_XSLOT), ring_y = (unsigned)(WP_XBYTES + half * WP3_NS * WR_YSLOT);
+    // the requests of (own) step s: X pieces 0..4 of one row (wave wq takes piece wq, wave 0 also piece 4), dY pieces 0..3
+    auto issue_step = [&](const Cursor& c, int s) {
+        const bool live = s < S;
+        const int yx = c.y + c.phase - 1;
+        const bool xrow_ok = live && (unsigned)yx < (unsigned)H;
+        const unsigned xbase = c.xoff + (unsigned)(c.phase - 1) * x_pitch;
+        const unsigned slot_x = ring_x + (unsigned)((s & (WP3_NS - 1)) * WR_XSLOT), slot_y = ring_y + (unsigned)((s & (WP3_NS - 1)) * WR_YSLOT);
+        const bool left_edge = c.x0 == 0, right_edge = c.x0 + 32 == W;
+        {
+            const bool ok = xrow_ok && x_ch_ok && !(left_edge && px_a == 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (__attribute__((address_space(3))) void*)(wp_smem + slot_x + (unsigned)wq * 1024u),
+                                                     16, (int)(ok ? xbase + xl_a : OOB), 0, 0, 0);
+        }
+        {
+            const bool real = wq == 0;
+            const bool ok = real && xrow_ok && x_ch_ok && px_b < 34 && !(right_edge && px_b == 33);
+            const unsigned m = real ? 0xffffffffu : 0u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (__attribute__((address_space(3))) void*)(wp_smem + (((slot_x + 4096u) & m) | ((unsigned)WP_DUMMY & ~m))),
+                                                     16, (int)(ok ? xbase + xl_b : OOB), 0, 0, 0);
+        }
+        {
+            const bool real = live && c.phase == 2;
+            const unsigned off = (real && y_ch_ok) ? c.yoff + (unsigned)(c.y >> up) * y_pitch + yl : OOB;
+            const unsigned m = real ? 0xffffffffu : 0u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(y_rsrc, (__attribute__((address_space(3))) void*)(wp_smem + (((slot_y + (unsigned)wq * 1024u) & m) | ((unsigned)WP_DUMMY & ~m))),
+                                                     16, (int)off, 0, 0, 0);
+        }
+    };
+
+    const int i16 = lane & 15, g = lane >> 4;
+    const int prow = g * 4 + (i16 >> 2);
+    unsigned a_off[4], b_off[3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_off[i] = (unsigned)(prow * 128 + ((i ^ ((prow >> 1) & 3)) << 5) + (i16 & 3) * 8);
+#pragma unroll
+    for (int ds = 0; ds < 3; ++ds) b_off[ds] = (unsigned)((prow + ds) * 128 + ((wq ^ (((prow + ds) >> 1) & 3)) << 5) + (i16 & 3) * 8);
+
+    f32x4_t acc[9][4], accb[4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[t][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accb[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = a.dbias != nullptr && ci0 == 0 && wq == 0;
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
+
+    // ---- cursors: rq = the step being requested (D steps ahead), (cy, cphase) = row / phase of the step being computed
+    Cursor rq;
+    {
+        const int r0 = R1 > R0 ? R0 : 0;
+        const int col = r0 / H;
+        rq.y = r0 - col * H; rq.n = col / strips; rq.x0 = (col - rq.n * strips) * 32; rq.phase = 0;
+        rebase(rq);
+    }
+    int cy = rq.y, cphase = 0;
+#pragma unroll
+    for (int d = 0; d < WP3_D; ++d) { issue_step(rq, d); advance(rq); }
+    wr_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (half) __builtin_amdgcn_s_barrier();                 // this half runs one segment behind
+
+    uint2 Blo[3][3], Bhi[3][3];                              // [register set][tap column]
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { Blo[q][k] = make_uint2(0, 0); Bhi[q][k] = make_uint2(0, 0); }
+
+    for (int s0 = 0; s0 < S_pad; s0 += 3) {
+        wr_static_for<3>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;                 // register set written in this step = step index mod 3
+            const int s = s0 + q;
+            const bool compute = s < S && cphase == 2;
+            // ================= LOAD segment =================
+            uint2 alo[4], ahi[4];
+            const unsigned slot = (unsigned)(s & (WP3_NS - 1));
+            const unsigned bbase = lds_base + ring_x + slot * WR_XSLOT;
+            const unsigned ab = lds_base + ring_y + slot * WR_YSLOT;
+            if constexpr (q == 0) { WP3_BREAD("196:197", "198:199", "200:201", "202:203", "204:205", "206:207", 0) }
+            else if constexpr (q == 1) { WP3_BREAD("208:209", "210:211", "212:213", "214:215", "216:217", "218:219", 1) }
+            else { WP3_BREAD("220:221", "222:223", "224:225", "226:227", "228:229", "230:231", 2) }
+            if (compute) {
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:0" : "={v[180:181]}"(alo[0]) : "v"(ab + a_off[0]));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "={v[182:183]}"(ahi[0]) : "v"(ab + a_off[0]));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:0" : "={v[184:185]}"(alo[1]) : "v"(ab + a_off[1]));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "={v[186:187]}"(ahi[1]) : "v"(ab + a_off[1]));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:0" : "={v[188:189]}"(alo[2]) : "v"(ab + a_off[2]));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "={v[190:191]}"(ahi[2]) : "v"(ab + a_off[2]));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:0" : "={v[192:193]}"(alo[3]) : "v"(ab + a_off[3]));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "={v[194:195]}"(ahi[3]) : "v"(ab + a_off[3]));
+            }
+            issue_step(rq, s + WP3_D);
+            advance(rq);
+            wr_wait_vmcnt<6>();                             // the requests of this and of the previous LOAD segment may fly: step s + 1 has landed
+            wr_wait_lgkm<0>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ================= MFMA segment: tap row 0 / 1 / 2 = the sets written two / one / zero steps ago =================
+            if (compute) {
+                __builtin_amdgcn_s_setprio(1);
+                wr_static_for<9>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value, dr = t / 3, ds = t % 3, set = (q + 1 + dr) % 3;
+                    const bf16x8_t bf = wr_frag(Blo[set][ds], Bhi[set][ds]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr_frag(alo[i], ahi[i]), bf, acc[t][i], 0, 0, 0);
+                });
+                if (do_bias) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr_frag(alo[i], ahi[i]), ones, accb[i], 0, 0, 0);
+                }
+                __builtin_amdgcn_s_setprio(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // the phase / row of the next step of this half
+            if (cphase < 2) ++cphase;
+            else if (++cy == H) { cy = 0; cphase = 0; }
+        });
+    }
+    if (!half) __builtin_amdgcn_s_barrier();               // the barrier the other half passes after its last segment
+
+    // ---- the second half's accumulators join the first half's through LDS (two passes of 72 registers + the bias sums)
+    wr_wait_vmcnt<0>();
+    __syncthreads();
+    float* xch = reinterpret_cast<float*>(wp_smem);
+    const int ltid = tid & 255;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (half) {
+            int k = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (((t * 4 + i) & 1) == pass) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) xch[(k * 4 + r) * 256 + ltid] = acc[t][i][r];
+                        ++k;
+                    }
+                }
+        }
+        __syncthreads();
+        if (!half) {
+            int k = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (((t * 4 + i) & 1) == pass) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[t][i][r] += xch[(k * 4 + r) * 256 + ltid];
+                        ++k;
+                    }
+                }
+        }
+        __syncthreads();
+    }
+    if (a.dbias != nullptr && ci0 == 0) {
+        if (half) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xch[(i * 4 + r) * 256 + ltid] = accb[i][r];
+        }
+        __syncthreads();
+        if (!half) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) accb[i][r] += xch[(i * 4 + r) * 256 + ltid];
+        }
+    }
+    if (half) return;
+    if (a.slabs != nullptr) {
+        float* slab = a.slabs + ((long)blockIdx.y * gridDim.x + blockIdx.x) * (9 * 64 * 64) + wq * 16 + i16;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slab[(t * 64 + i * 16 + g * 4 + r) * 64] = acc[t][i][r] * oscale;
+    }
+    const int ci = ci0 + wq * 16 + i16;
+    if (a.slabs == nullptr && ci < CIN) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + i * 16 + g * 4 + r;
+                    if (co < a.COUT) atomicAdd(a.dw + ((long)co * 9 + t) * CIN + ci, acc[t][i][r] * oscale);
+                }
+    }
+    if (do_bias && i16 == 0) {
+        float* bp = a.bias_part != nullptr ? a.bias_part + ((long)(blockIdx.y / a.ci_tiles) * gridDim.x + blockIdx.x) * 64 : nullptr;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = i * 16 + g * 4 + r;
+                if (bp != nullptr) bp[col] = accb[i][r] * oscale;
+                else if (co0 + col < a.COUT) atomicAdd(a.dbias + co0 + col, accb[i][r] * oscale);
+            }
+    }
+}
+
 // dW[co][tap][ci] += sum over the nblk slabs of pair blockIdx.y; blockIdx.z takes every gridDim.z-th slab (a pair with
 // hundreds of slabs would otherwise be summed by 36 blocks in one long dependent chain) and the few partial sums meet in
 // dW through atomics.
@@ -775,13 +1061,15 @@ int sp_wgrad_rows_launch(const void* x, const void* dy, float* dw, float* dbias,
         static bool pp_attr = false;
         if (!pp_attr) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WP_LDS);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_pp3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WP_LDS);
             if (e != hipSuccess) { sp_set_error("hipFuncSetAttribute(LDS=%d) failed: %s", WP_LDS, hipGetErrorString(e)); return SP_ERR_LAUNCH; }
             pp_attr = true;
         }
         a.slabs = use_slabs && (long)nb * pairs <= 512 ? ws : nullptr;
         a.bias_part = (a.slabs != nullptr && dbias != nullptr) ? ws + 512L * 9 * 64 * 64 : nullptr;
         a.thin_mode = 0;
-        hipLaunchKernelGGL(conv_wgrad_pp_kernel, dim3((unsigned)nb, (unsigned)pairs), dim3(512), WP_LDS, s, a, rpb, rows_total);
+        if (sp_tune(SP_TUNE_WGRAD_PP, 1) == 2) hipLaunchKernelGGL(conv_wgrad_pp_kernel, dim3((unsigned)nb, (unsigned)pairs), dim3(512), WP_LDS, s, a, rpb, rows_total);
+        else hipLaunchKernelGGL(conv_wgrad_pp3_kernel, dim3((unsigned)nb, (unsigned)pairs), dim3(512), WP_LDS, s, a, rpb, rows_total);
         if (a.slabs != nullptr) {
             int z = 512 / (36 * pairs);
             if (z > nb / 4) z = nb / 4;
