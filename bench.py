@@ -21,6 +21,7 @@ VGG-16, Adam lr 1e-5.  Prints ONE JSON line on rank 0.  Beside the headline it c
 import argparse
 import gc
 import json
+import re
 import os
 import subprocess
 import sys
@@ -36,7 +37,7 @@ sys.path.insert(0, ROOT)
 GFLOP_PER_IMAGE = {1: 409.74, 2: 197.75, 0.5: 1239.60}
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}      # dense MFMA peaks, MI355X_MICROARCH.md
 DOMINANT_KERNEL = "conv3x3_pp_kernel<bf16,2> (sp_conv2d_igemm, 3x3, Cout>64, 128 co x 8x32 px tiles, ping-pong schedule)"
-DOMINANT_KERNEL_SYMBOL = "conv3x3_pp_kernel<bf16, 2"
+DOMINANT_KERNEL_SYMBOL = r"conv3x3_pp_kernel<bf16, 2, [^>]*, 2>\("      # regex: both epilogue forms on 32-wide tiles (not the 16-wide form)
 TRAFFIC_FILES = ("round3_hbm_traffic_per_kernel.json", "round2_hbm_traffic_per_kernel.json")
 
 
@@ -179,7 +180,7 @@ def recorded_traffic(symbols):
             continue
         for symbol in symbols:
             # every instantiation of the kernel that serves the dominant launches (e.g. its two epilogue forms), launch-weighted
-            hits = [(kname, rec) for kname, rec in kernels.items() if symbol in kname]
+            hits = [(kname, rec) for kname, rec in kernels.items() if re.search(symbol, kname)]
             if hits:
                 n = sum(rec.get("launches_profiled") or 1 for _, rec in hits)
                 avg = sum(rec["hbm_bytes_per_launch"] * (rec.get("launches_profiled") or 1) for _, rec in hits) / n
