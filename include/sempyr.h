@@ -45,8 +45,13 @@ int sp_version(void);
  *   SP_TUNE_IGEMM_DMA        0 = never use the LDS-DMA igemm kernel, 1 = small-spatial 3x3 layers (default), 2 = everywhere
  *   SP_TUNE_WGRAD_ROWS       0 = never use the row-walker 3x3 weight-gradient kernel, 1 = maps >= 32 wide and 16 x 16 maps (default),
  *                            2 = maps >= 32 wide only, 3 = 8 x 8 maps too
- *   SP_TUNE_DETERMINISTIC    1 = every floating-point reduction runs in a fixed order (per-split partial slabs + ordered
- *                            reduce instead of fp32 atomics): bit-identical results run to run; 0 = atomics where they are
+ *   SP_TUNE_DETERMINISTIC    1 = the reductions behind gradients, parameters and normalisation statistics run in a fixed
+ *                            order (per-split partial slabs + ordered reduce instead of fp32 atomics): those tensors are
+ *                            bit-identical run to run (tests/test_gpu_step.py).  NOT covered: the scalar loss VALUES (fp64
+ *                            atomics over blocks: equal to ~1e-16 relative, not bit for bit) and the <dW, W> dot of
+ *                            sp_conv2d_wgrad_fused; a row-walker launch whose workspace is too small for its slabs does not
+ *                            happen in this mode (the ordered per-tap kernels take the layer; sp_conv2d_wgrad_accum_pooled,
+ *                            which has no other kernel, reports an error) - no silent fall-back to atomics.  0 = atomics where they are
  *                            faster; default (-1): on for SP_F32 storage (the parity mode), off for SP_BF16
  *   SP_TUNE_SPLITK_TARGET / _MINSTEPS     split-K plan of the small-spatial 3x3 forward / input-gradient layers (640 / 6)
  *   SP_TUNE_CONV1X1_DIRECT   0 = 1x1 layers on the tiled igemm kernel (default 1: direct kernel)

@@ -1028,6 +1028,7 @@ int sp_wgrad_rows_launch(const void* x, const void* dy, float* dw, float* dbias,
     const bool det = sp_deterministic(SP_BF16);
     const int env_slabs = det ? 1 : sp_tune(SP_TUNE_WGRAD_ROWS_SLABS, 1);
     const bool use_slabs = env_slabs && ws != nullptr && ws_floats >= 512L * (9 * 64 * 64 + 64) && cin % 4 == 0 && (env_slabs == 1 || pairs <= env_slabs);
+    if (det && !use_slabs) return 1;                       // deterministic mode never merges with atomics: the caller's ordered per-tap path takes the layer
     const double flops = 2.0 * n * h * w * 9.0 * (64.0 * co_tiles) * (64.0 * a.ci_tiles);
     // with slabs the merge is a plain 147 KB store per block + one reduce pass (no serialisation): fill the chip
     int total = env_blocks > 0 ? env_blocks : (use_slabs ? 512 : (int)(sqrt(flops * 2.45e-6) + 0.5));

@@ -245,6 +245,7 @@ class ModelWrapper(object):
         gc.collect()                       # no autograd nodes of earlier (eager-stream) iterations may survive into the capture
         torch.cuda.synchronize()
         st = self._graph_state = {}
+        st["flat_ptrs"] = self._flat_ptrs()
         st["images"], st["labels"], st["masks"] = images_real.clone(), labels.clone(), [m.clone() for m in masks]
         st["w"] = (w_rec, w_div)
         zdim = (images_real.shape[0], self.latent_dimensions)
@@ -272,12 +273,25 @@ class ModelWrapper(object):
                      "loss_generator": l_g.detach(), "loss_generator_semantic_reconstruction": l_rec.detach().reshape(()),
                      "loss_generator_diversity": l_div.detach(), "images_fake": fake.detach()}
 
+    def _flat_ptrs(self):
+        """Addresses of the two networks' flat gradient buffers (None where not allocated): what captured graphs are tied to."""
+        out = []
+        for net in (self.generator, self.discriminator):
+            bank = getattr(net, "_bank", None)
+            flat = getattr(bank, "flat", None) if bank is not None else None
+            out.append(flat.data_ptr() if flat is not None else None)
+        return tuple(out)
+
     def train_step_graphed(self, images_real: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None, masks=None,
                            noise_d: Optional[torch.Tensor] = None, noise_g: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """train_step() through the captured graphs (capture_graphs() first).  images / labels / masks: new batch to copy into
         the graphs' static inputs, or None to reuse the resident one.  The returned tensors are the graphs' static outputs:
         they are overwritten by the next call."""
         st = self._graph_state
+        if st is None or st.get("flat_ptrs") != self._flat_ptrs():
+            self._graph_state = None
+            raise RuntimeError("train_step_graphed(): the networks' flat gradient buffers were re-allocated after capture_graphs() "
+                               "(parameters or compute dtype changed) - capture again")
         if noise_d is None:
             st["noise_d"].normal_()
         else:
@@ -331,6 +345,9 @@ class ModelWrapper(object):
         after = self.graph_after_iterations
         sig = self._batch_signature(images_real, labels, masks)
         st = self._graph_state
+        if st is not None and st.get("flat_ptrs") != self._flat_ptrs():
+            st = self._graph_state = None                       # gradient buffers re-allocated: eager steps, then a fresh capture
+            self._eager_run = 0
         if st is not None and st.get("sig") == sig and st.get("w") == (w_rec, w_div):
             return self.train_step_graphed(images_real, labels, masks)
         out = self.train_step(images_real, labels, masks, w_rec=w_rec, w_div=w_div)

@@ -419,7 +419,12 @@ class SpectralNormBank:
             self.extra_offs.append(flat_off)
             flat_off += pad_to(p.numel(), 4)
         self.arena_floats, self.flat_floats, self.max_elems = arena_off, flat_off, max_elems
-        self.flat = None                           # (re)allocated by enter_backward()
+        # a rebuild (compute-dtype switch, re-allocated parameters) keeps the flat gradient buffer when its size is unchanged: captured
+        # graphs, the Adam plans and the parameters' .grad views all point into it (round-2 ADVICE: a silent re-allocation would leave
+        # them on the old buffer while the reducer averaged the new, empty one); a changed size drops it - model_wrapper then refuses
+        # to replay graphs captured on the old one
+        old_flat = getattr(self, "flat", None)
+        self.flat = old_flat if (old_flat is not None and old_flat.numel() == flat_off and old_flat.device == torch.device(device)) else None
         self.bwd_table_dev = torch.frombuffer(bytearray(bytes(btab)), dtype=torch.uint8).to(device)
 
     def begin(self, training: bool, dtype, device) -> SNCall:
