@@ -670,7 +670,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_pp_kernel(WrArgs a, int rows_p
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:0" : "={v[" LO2 "]}"(Blo[SET][2]) : "v"(bbase + b_off[2]));                     \
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "={v[" HI2 "]}"(Bhi[SET][2]) : "v"(bbase + b_off[2]));
 
-constexpr int WP3_NS = 4, WP3_D = 3;                       // ring slots per half, request distance in (own) steps
+#ifndef WP3_NS_
+#define WP3_NS_ 4
+#endif
+constexpr int WP3_NS = WP3_NS_, WP3_D = WP3_NS - 1;        // ring slots per half, request distance in (own) steps (<= NS - 1)
+constexpr int WP3_XBYTES = 2 * WP3_NS * WR_XSLOT, WP3_DUMMY = WP3_XBYTES + 2 * WP3_NS * WR_YSLOT;
+constexpr int WP3_LDS = (WP3_DUMMY + 1024) > WP_LDS ? (WP3_DUMMY + 1024) : WP_LDS;      // (the accumulator hand-over needs 73 728 B)
+template <bool TIMING>
 __global__ __launch_bounds__(512) void conv_wgrad_pp3_kernel(WrArgs a, int rows_per_block, int rows_total) {
     extern __shared__ __attribute__((aligned(16))) char wp_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -700,7 +706,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_pp3_kernel(WrArgs a, int rows_
     const int up = a.dy_up2 ? 1 : 0;
     const int HY = H >> up, WY = W >> up;
     const float oscale = up ? 0.25f : 1.f;
-    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.x), 0, __builtin_amdgcn_readfirstlane(a.N * H * W * CIN * 2), 0x00020000);
+    // X descriptor based ONE PIXEL BEFORE the tensor: a strip's row offset (pixel x0 - 1) is then never negative - it travels in the
+    // scalar offset operand, which the hardware adds as an unsigned 32-bit value (the pixel in front of image 0 is never requested)
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(reinterpret_cast<const char*>(a.x) - CIN * 2), 0, __builtin_amdgcn_readfirstlane((a.N * H * W + 1) * CIN * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.dy), 0, __builtin_amdgcn_readfirstlane(a.N * HY * WY * a.LD_DY * 2), 0x00020000);
 
     const int dpx = lane >> 3;
@@ -709,53 +717,52 @@ __global__ __launch_bounds__(512) void conv_wgrad_pp3_kernel(WrArgs a, int rows_
     const bool y_ch_ok = co0 + dls * 8 < a.LD_DY;
     const unsigned x_lane = (unsigned)((ci0 + dls * 8) * 2), y_lane = (unsigned)((co0 + dls * 8) * 2);
 
-    struct Cursor { int n, x0, y, phase; unsigned xoff, yoff; };
+    // Request cursor, kept cheap: the LOAD segment of a step was 814 cycles, most of them ~110 dependent scalar instructions of
+    // cursor and predicate arithmetic (the MFMA segment it pairs with: 640).  Now everything that depends on the lane or on the
+    // column is computed where a column starts (voff_*: per-lane offsets with the channel / image-edge exclusions folded in as
+    // out-of-range values), a row advances two scalar offsets, the row offset travels in the instruction's SCALAR offset operand,
+    // and a row outside the image / past the end of the walk selects an empty descriptor (everything reads as zero).
+    struct Cursor { int n, x0, y, phase; unsigned xrow, yrow; bool x_ok; };   // xrow: X row fetched by this step (pixel x0 - 1), yrow: dY row y
     const unsigned x_pitch = (unsigned)(W * CIN * 2), y_pitch = (unsigned)(WY * a.LD_DY * 2);
-    auto rebase = [&](Cursor& c) {
-        c.xoff = (unsigned)(((c.n * H + c.y) * W + c.x0 - 1) * CIN * 2);
-        c.yoff = (unsigned)(((c.n * HY) * WY + (c.x0 >> up)) * a.LD_DY * 2);
+    const int px_a = wq * 8 + dpx, px_b = 32 + dpx;
+    const unsigned xl_a = (unsigned)(px_a * CIN * 2) + x_lane, xl_b = (unsigned)(px_b * CIN * 2) + x_lane;
+    const unsigned yl = y_ch_ok ? (unsigned)((((wq * 8 + dpx) >> up) * a.LD_DY) * 2) + y_lane : OOB;
+    unsigned voff_a = OOB, voff_b = OOB;                    // per-lane offsets of X pieces wq and 4 inside a row (this column)
+    const __amdgpu_buffer_rsrc_t null_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.x), 0, 0, 0x00020000);
+    auto column = [&](Cursor& c) {                          // a column starts: (n, x0, y) set, phase 0
+        const long row = ((long)c.n * H + c.y - 1) * W + c.x0;              // the first step fetches X row y - 1 (descriptor: one pixel early)
+        c.xrow = (unsigned)(row * CIN * 2);                                  // (row -1 of image 0 wraps: that step selects the empty descriptor)
+        c.yrow = (unsigned)((((c.n * HY) + (c.y >> up)) * WY + (c.x0 >> up)) * a.LD_DY * 2);
+        c.x_ok = c.y > 0;
+        const bool left_edge = c.x0 == 0, right_edge = c.x0 + 32 == W;
+        voff_a = (x_ch_ok && !(left_edge && px_a == 0)) ? xl_a : OOB;
+        voff_b = (wq == 0 && x_ch_ok && px_b < 34 && !(right_edge && px_b == 33)) ? xl_b : OOB;
     };
     auto advance = [&](Cursor& c) {
-        if (c.phase < 2) { ++c.phase; return; }
-        c.xoff += x_pitch;
+        c.xrow += x_pitch;
+        if (c.phase < 2) { ++c.phase; c.x_ok = c.y + c.phase - 1 < H; return; }
+        if (up == 0 || (c.y & 1)) c.yrow += y_pitch;
         if (++c.y == H) {
             c.y = 0; c.phase = 0;
             c.x0 += 32;
             if (c.x0 == W) { c.x0 = 0; ++c.n; }
-            rebase(c);
+            column(c);
+        } else {
+            c.x_ok = c.y + 1 < H;
         }
     };
-    const int px_a = wq * 8 + dpx, px_b = 32 + dpx;
-    const unsigned xl_a = (unsigned)(px_a * CIN * 2) + x_lane, xl_b = (unsigned)(px_b * CIN * 2) + x_lane;
-    const unsigned yl = (unsigned)((((wq * 8 + dpx) >> up) * a.LD_DY) * 2) + y_lane;
-    const unsigned ring_x = (unsigned)(half * WP3_NS * WR_XSLOT), ring_y = (unsigned)(WP_XBYTES + half * WP3_NS * WR_YSLOT);
+    const unsigned ring_x = (unsigned)(half * WP3_NS * WR_XSLOT), ring_y = (unsigned)(WP3_XBYTES + half * WP3_NS * WR_YSLOT);
+    const unsigned lds_b = wq == 0 ? 4096u : 0u;            // piece 4 of an X row: wave 0 only (the others: a dropped request into the dummy KB)
     // the requests of (own) step s: X pieces 0..4 of one row (wave wq takes piece wq, wave 0 also piece 4), dY pieces 0..3
     auto issue_step = [&](const Cursor& c, int s) {
         const bool live = s < S;
-        const int yx = c.y + c.phase - 1;
-        const bool xrow_ok = live && (unsigned)yx < (unsigned)H;
-        const unsigned xbase = c.xoff + (unsigned)(c.phase - 1) * x_pitch;
-        const unsigned slot_x = ring_x + (unsigned)((s & (WP3_NS - 1)) * WR_XSLOT), slot_y = ring_y + (unsigned)((s & (WP3_NS - 1)) * WR_YSLOT);
-        const bool left_edge = c.x0 == 0, right_edge = c.x0 + 32 == W;
-        {
-            const bool ok = xrow_ok && x_ch_ok && !(left_edge && px_a == 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (__attribute__((address_space(3))) void*)(wp_smem + slot_x + (unsigned)wq * 1024u),
-                                                     16, (int)(ok ? xbase + xl_a : OOB), 0, 0, 0);
-        }
-        {
-            const bool real = wq == 0;
-            const bool ok = real && xrow_ok && x_ch_ok && px_b < 34 && !(right_edge && px_b == 33);
-            const unsigned m = real ? 0xffffffffu : 0u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (__attribute__((address_space(3))) void*)(wp_smem + (((slot_x + 4096u) & m) | ((unsigned)WP_DUMMY & ~m))),
-                                                     16, (int)(ok ? xbase + xl_b : OOB), 0, 0, 0);
-        }
-        {
-            const bool real = live && c.phase == 2;
-            const unsigned off = (real && y_ch_ok) ? c.yoff + (unsigned)(c.y >> up) * y_pitch + yl : OOB;
-            const unsigned m = real ? 0xffffffffu : 0u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(y_rsrc, (__attribute__((address_space(3))) void*)(wp_smem + (((slot_y + (unsigned)wq * 1024u) & m) | ((unsigned)WP_DUMMY & ~m))),
-                                                     16, (int)off, 0, 0, 0);
-        }
+        const unsigned slot = (unsigned)(s & (WP3_NS - 1));
+        const unsigned slot_x = ring_x + slot * WR_XSLOT, slot_y = ring_y + slot * WR_YSLOT;
+        const __amdgpu_buffer_rsrc_t rx = (live && c.x_ok) ? x_rsrc : null_rsrc;
+        const __amdgpu_buffer_rsrc_t ry = (live && c.phase == 2) ? y_rsrc : null_rsrc;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(wp_smem + slot_x + (unsigned)wq * 1024u), 16, (int)voff_a, (int)c.xrow, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(wp_smem + (wq == 0 ? slot_x + lds_b : (unsigned)WP3_DUMMY)), 16, (int)voff_b, (int)c.xrow, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (__attribute__((address_space(3))) void*)(wp_smem + slot_y + (unsigned)wq * 1024u), 16, (int)yl, (int)c.yrow, 0, 0);
     };
 
     const int i16 = lane & 15, g = lane >> 4;
@@ -782,7 +789,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_pp3_kernel(WrArgs a, int rows_
         const int r0 = R1 > R0 ? R0 : 0;
         const int col = r0 / H;
         rq.y = r0 - col * H; rq.n = col / strips; rq.x0 = (col - rq.n * strips) * 32; rq.phase = 0;
-        rebase(rq);
+        column(rq);
     }
     int cy = rq.y, cphase = 0;
 #pragma unroll
@@ -791,6 +798,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_pp3_kernel(WrArgs a, int rows_
     __builtin_amdgcn_s_barrier();
     if (half) __builtin_amdgcn_s_barrier();                 // this half runs one segment behind
 
+    // TIMING build (SP_TUNE_WGRAD_PP = 3): cycles per wave in [0] LOAD segment up to the request issue, [1] vmcnt wait, [2] lgkm wait,
+    // [3] barrier after LOAD, [4] MFMA segment, [5] barrier after MFMA; written to the slab area instead of the tile
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+    auto stamp = [&](int k) {
+        if constexpr (TIMING) { const unsigned long long t = __builtin_readcyclecounter(); tacc[k] += t - tprev; tprev = t; }
+    };
+    if constexpr (TIMING) tprev = __builtin_readcyclecounter();
     uint2 Blo[3][3], Bhi[3][3];                              // [register set][tap column]
 #pragma unroll
     for (int q = 0; q < 3; ++q)
@@ -810,7 +824,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_pp3_kernel(WrArgs a, int rows_
             if constexpr (q == 0) { WP3_BREAD("196:197", "198:199", "200:201", "202:203", "204:205", "206:207", 0) }
             else if constexpr (q == 1) { WP3_BREAD("208:209", "210:211", "212:213", "214:215", "216:217", "218:219", 1) }
             else { WP3_BREAD("220:221", "222:223", "224:225", "226:227", "228:229", "230:231", 2) }
-            if (compute) {
+            if (compute && !(TIMING && a.thin_mode == 9)) {
                 asm volatile("ds_read_b64_tr_b16 %0, %1 offset:0" : "={v[180:181]}"(alo[0]) : "v"(ab + a_off[0]));
                 asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "={v[182:183]}"(ahi[0]) : "v"(ab + a_off[0]));
                 asm volatile("ds_read_b64_tr_b16 %0, %1 offset:0" : "={v[184:185]}"(alo[1]) : "v"(ab + a_off[1]));
@@ -820,12 +834,16 @@ __global__ __launch_bounds__(512) void conv_wgrad_pp3_kernel(WrArgs a, int rows_
                 asm volatile("ds_read_b64_tr_b16 %0, %1 offset:0" : "={v[192:193]}"(alo[3]) : "v"(ab + a_off[3]));
                 asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "={v[194:195]}"(ahi[3]) : "v"(ab + a_off[3]));
             }
-            issue_step(rq, s + WP3_D);
+            if (!(TIMING && a.thin_mode == 8)) issue_step(rq, s + WP3_D);
             advance(rq);
-            wr_wait_vmcnt<6>();                             // the requests of this and of the previous LOAD segment may fly: step s + 1 has landed
+            stamp(0);
+            wr_wait_vmcnt<3 * (WP3_D - 1)>();               // the requests of the last D - 1 LOAD segments may fly: step s + 1 has landed
+            stamp(1);
             wr_wait_lgkm<0>();
+            stamp(2);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+            stamp(3);
             // ================= MFMA segment: tap row 0 / 1 / 2 = the sets written two / one / zero steps ago =================
             if (compute) {
                 __builtin_amdgcn_s_setprio(1);
@@ -843,14 +861,24 @@ __global__ __launch_bounds__(512) void conv_wgrad_pp3_kernel(WrArgs a, int rows_
                 __builtin_amdgcn_s_setprio(0);
             }
             __builtin_amdgcn_sched_barrier(0);
+            stamp(4);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+            stamp(5);
             // the phase / row of the next step of this half
             if (cphase < 2) ++cphase;
             else if (++cy == H) { cy = 0; cphase = 0; }
         });
     }
     if (!half) __builtin_amdgcn_s_barrier();               // the barrier the other half passes after its last segment
+    if constexpr (TIMING) {
+        if (lane == 0 && a.slabs != nullptr) {
+            float* out = a.slabs + (((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 8;
+            for (int k = 0; k < 6; ++k) out[k] = (float)tacc[k];
+            out[6] = (float)S;
+        }
+        return;
+    }
 
     // ---- the second half's accumulators join the first half's through LDS (two passes of 72 registers + the bias sums)
     wr_wait_vmcnt<0>();
@@ -1062,7 +1090,8 @@ int sp_wgrad_rows_launch(const void* x, const void* dy, float* dw, float* dbias,
         static bool pp_attr = false;
         if (!pp_attr) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WP_LDS);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_pp3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WP_LDS);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_pp3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WP3_LDS);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_pp3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, WP3_LDS);
             if (e != hipSuccess) { sp_set_error("hipFuncSetAttribute(LDS=%d) failed: %s", WP_LDS, hipGetErrorString(e)); return SP_ERR_LAUNCH; }
             pp_attr = true;
         }
@@ -1070,7 +1099,8 @@ int sp_wgrad_rows_launch(const void* x, const void* dy, float* dw, float* dbias,
         a.bias_part = (a.slabs != nullptr && dbias != nullptr) ? ws + 512L * 9 * 64 * 64 : nullptr;
         a.thin_mode = 0;
         if (sp_tune(SP_TUNE_WGRAD_PP, 1) == 2) hipLaunchKernelGGL(conv_wgrad_pp_kernel, dim3((unsigned)nb, (unsigned)pairs), dim3(512), WP_LDS, s, a, rpb, rows_total);
-        else hipLaunchKernelGGL(conv_wgrad_pp3_kernel, dim3((unsigned)nb, (unsigned)pairs), dim3(512), WP_LDS, s, a, rpb, rows_total);
+        else if (sp_tune(SP_TUNE_WGRAD_PP, 1) == 3) { a.thin_mode = sp_tune(SP_TUNE_WGRAD_ROWS_THIN, 0); hipLaunchKernelGGL(conv_wgrad_pp3_kernel<true>, dim3((unsigned)nb, (unsigned)pairs), dim3(512), WP3_LDS, s, a, rpb, rows_total); SP_LAUNCH_CHECK(); return SP_OK; }
+        else hipLaunchKernelGGL(conv_wgrad_pp3_kernel<false>, dim3((unsigned)nb, (unsigned)pairs), dim3(512), WP3_LDS, s, a, rpb, rows_total);
         if (a.slabs != nullptr) {
             int z = 512 / (36 * pairs);
             if (z > nb / 4) z = nb / 4;
