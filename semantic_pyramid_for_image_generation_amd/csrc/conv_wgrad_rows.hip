@@ -753,16 +753,26 @@ __global__ __launch_bounds__(512) void conv_wgrad_pp3_kernel(WrArgs a, int rows_
     };
     const unsigned ring_x = (unsigned)(half * WP3_NS * WR_XSLOT), ring_y = (unsigned)(WP3_XBYTES + half * WP3_NS * WR_YSLOT);
     const unsigned lds_b = wq == 0 ? 4096u : 0u;            // piece 4 of an X row: wave 0 only (the others: a dropped request into the dummy KB)
-    // the requests of (own) step s: X pieces 0..4 of one row (wave wq takes piece wq, wave 0 also piece 4), dY pieces 0..3
-    auto issue_step = [&](const Cursor& c, int s) {
+    // the requests of (own) step s: X pieces 0..4 of one row (wave wq takes piece wq, wave 0 also piece 4), dY pieces 0..3.
+    // PREPARED (descriptor choice, LDS targets, row offsets: all scalar) in the MFMA segment of the step before - scalar
+    // instructions issue between MFMAs for free, in the LOAD segment they were a third of its length - and ISSUED in the LOAD segment.
+    __amdgpu_buffer_rsrc_t rq_rx = null_rsrc, rq_ry = null_rsrc;
+    unsigned rq_lds_a = 0, rq_lds_b = 0, rq_lds_y = 0, rq_xrow = 0, rq_yrow = 0;
+    auto prepare = [&](const Cursor& c, int s) {
         const bool live = s < S;
         const unsigned slot = (unsigned)(s & (WP3_NS - 1));
         const unsigned slot_x = ring_x + slot * WR_XSLOT, slot_y = ring_y + slot * WR_YSLOT;
-        const __amdgpu_buffer_rsrc_t rx = (live && c.x_ok) ? x_rsrc : null_rsrc;
-        const __amdgpu_buffer_rsrc_t ry = (live && c.phase == 2) ? y_rsrc : null_rsrc;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(wp_smem + slot_x + (unsigned)wq * 1024u), 16, (int)voff_a, (int)c.xrow, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(wp_smem + (wq == 0 ? slot_x + lds_b : (unsigned)WP3_DUMMY)), 16, (int)voff_b, (int)c.xrow, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (__attribute__((address_space(3))) void*)(wp_smem + slot_y + (unsigned)wq * 1024u), 16, (int)yl, (int)c.yrow, 0, 0);
+        rq_rx = (live && c.x_ok) ? x_rsrc : null_rsrc;
+        rq_ry = (live && c.phase == 2) ? y_rsrc : null_rsrc;
+        rq_lds_a = slot_x + (unsigned)wq * 1024u;
+        rq_lds_b = wq == 0 ? slot_x + lds_b : (unsigned)WP3_DUMMY;
+        rq_lds_y = slot_y + (unsigned)wq * 1024u;
+        rq_xrow = c.xrow; rq_yrow = c.yrow;
+    };
+    auto issue = [&]() {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq_rx, (__attribute__((address_space(3))) void*)(wp_smem + rq_lds_a), 16, (int)voff_a, (int)rq_xrow, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq_rx, (__attribute__((address_space(3))) void*)(wp_smem + rq_lds_b), 16, (int)voff_b, (int)rq_xrow, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq_ry, (__attribute__((address_space(3))) void*)(wp_smem + rq_lds_y), 16, (int)yl, (int)rq_yrow, 0, 0);
     };
 
     const int i16 = lane & 15, g = lane >> 4;
@@ -793,7 +803,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_pp3_kernel(WrArgs a, int rows_
     }
     int cy = rq.y, cphase = 0;
 #pragma unroll
-    for (int d = 0; d < WP3_D; ++d) { issue_step(rq, d); advance(rq); }
+    for (int d = 0; d < WP3_D; ++d) { prepare(rq, d); issue(); advance(rq); }
+    prepare(rq, WP3_D);                                     // the requests of the first LOAD segment
     wr_wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (half) __builtin_amdgcn_s_barrier();                 // this half runs one segment behind
@@ -834,8 +845,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_pp3_kernel(WrArgs a, int rows_
                 asm volatile("ds_read_b64_tr_b16 %0, %1 offset:0" : "={v[192:193]}"(alo[3]) : "v"(ab + a_off[3]));
                 asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "={v[194:195]}"(ahi[3]) : "v"(ab + a_off[3]));
             }
-            if (!(TIMING && a.thin_mode == 8)) issue_step(rq, s + WP3_D);
-            advance(rq);
+            if (!(TIMING && a.thin_mode == 8)) issue();
             stamp(0);
             wr_wait_vmcnt<3 * (WP3_D - 1)>();               // the requests of the last D - 1 LOAD segments may fly: step s + 1 has landed
             stamp(1);
@@ -860,6 +870,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_pp3_kernel(WrArgs a, int rows_
                 }
                 __builtin_amdgcn_s_setprio(0);
             }
+            advance(rq);                                    // (scalar; voff_* change where a column starts)
+            prepare(rq, s + 1 + WP3_D);
             __builtin_amdgcn_sched_barrier(0);
             stamp(4);
             __builtin_amdgcn_s_barrier();
