@@ -124,6 +124,19 @@ def test_bank_flat_layout_covers_every_parameter_once():
         assert cov[0][0] == 0 and cov[-1][1] == bank.flat_floats and all(x[1] == y[0] for x, y in zip(cov, cov[1:]))
 
 
+def test_bank_rebuild_keeps_the_flat_gradient_buffer():
+    """A rebuild of the bank's tables (compute-dtype switch, re-packed weights) must not drop the flat gradient buffer while its
+    size is unchanged: captured graphs, the Adam plans and the parameters' .grad views point into it (round-2 ADVICE)."""
+    import semantic_pyramid_for_image_generation_amd as sp
+    net = sp.Discriminator(channel_factor=8)
+    bank = net._bank
+    bank._build(torch.float32, "cpu")
+    bank._alloc_flat("cpu")
+    ptr, floats = bank.flat.data_ptr(), bank.flat_floats
+    bank._build(torch.bfloat16, "cpu")
+    assert bank.flat is not None and bank.flat.data_ptr() == ptr and bank.flat_floats == floats
+
+
 def test_bench_spawns_its_own_ranks():
     """bench.py --gpus N without an outer launcher: N children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set and
     rendezvous on 127.0.0.1; the parent (which never touches the GPU) relays rank 0's output and the worst exit code."""
