@@ -152,6 +152,9 @@ __device__ __forceinline__ float pool2_combine(float x, float y, bool is_max) { 
 template <typename T>
 __device__ __forceinline__ void conv_epilogue_pool2(const sp_conv_params& p, const float (&a)[16], const float (&b)[16], int lane,
                                                     long ppix_row, int pcol0, int co, bool add_bias = true) {
+    // a co-tile past Cout (Cout % 16 == 0 is all the API asks of a pooled layer) has whole 16-channel groups outside the tensor: not
+    // stored (they would land on the next pooled pixel; lanes l and l ^ 1 share their group, so the exchange below stays paired)
+    if (co + 16 > p.cout) return;
     const bool odd = lane & 1;
     const bool is_max = p.pool2 == 2;
     float v[16];

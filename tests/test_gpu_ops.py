@@ -187,6 +187,8 @@ PP_EPILOGUE_CASES = [  # (n, cin, cout, hw, act, residuals, mask, pool2, input-u
     (2, 128, 128, 64, 0, 0, True, 0, False, False), (2, 128, 256, 64, 0, 2, False, 1, False, True), (2, 64, 128, 64, 2, 0, False, 2, False, True),
     (2, 256, 128, 64, 0, 0, True, 0, True, False), (5, 32, 192, 32, 3, 0, False, 0, False, True), (2, 64, 72, 32, 1, 0, False, 0, False, True),
     (20, 256, 512, 32, 1, 1, False, 0, False, True),
+    # pooling with a partial last channel tile (Cout % 16 == 0 is all the API asks): the groups past Cout must not be stored
+    (2, 64, 80, 64, 2, 0, False, 2, False, True), (3, 72, 192, 32, 0, 1, False, 1, False, True), (2, 64, 48, 64, 0, 0, False, 1, False, True),
     # Cout <= 64: the eight-row-pair-wave form
     (2, 64, 64, 64, 1, 0, False, 0, False, True), (3, 128, 64, 128, 0, 2, False, 0, False, True), (2, 72, 64, 32, 0, 0, True, 0, False, False),
     (2, 64, 64, 64, 2, 0, False, 2, False, True), (2, 64, 64, 64, 0, 1, False, 1, False, True), (3, 32, 40, 32, 1, 0, False, 0, False, True),
