@@ -11,16 +11,17 @@ random.seed(seed); torch.manual_seed(seed)
 worst = {}
 def note(kind, err, shape):
     if err > worst.get(kind, (0, None))[0]: worst[kind] = (err, shape)
-def conv(n, cin, cout, h, w, act, res, mask, pool2, bias):
-    x = ops.nhwc_empty(n, cin, h, w, dt, 'cuda').normal_()
+def conv(n, cin, cout, h, w, act, res, mask, pool2, bias, up=False):
+    x = ops.nhwc_empty(n, cin, h // 2 if up else h, w // 2 if up else w, dt, 'cuda').normal_()
     wt = (torch.randn(cout, 3, 3, cin, device='cuda') * 0.05).to(dt)
     b = torch.randn(cout, device='cuda') if bias else None
     ho, wo = (h // 2, w // 2) if pool2 else (h, w)
     mk = lambda: ops.nhwc_empty(n, cout, ho, wo, dt, 'cuda').normal_()
     r1 = mk() if res >= 1 else None; r2 = mk() if res >= 2 else None; ms = mk() if mask else None
     y = ops.nhwc_empty(n, cout, ho, wo, dt, 'cuda').fill_(-7.0)
-    ops._conv_launch(x, wt.data_ptr(), b, y, r1, r2, ms, 0.2, n, h, w, cin, cout, cout, 3, act, dt, pool2, False)
-    ref = F.conv2d(x.float(), wt.float().permute(0, 3, 1, 2), b, padding=1)
+    ops._conv_launch(x, wt.data_ptr(), b, y, r1, r2, ms, 0.2, n, h, w, cin, cout, cout, 3, act, dt, pool2, up)
+    xin = 0.25 * F.interpolate(x.float(), scale_factor=2, mode='nearest') if up else x.float()
+    ref = F.conv2d(xin, wt.float().permute(0, 3, 1, 2), b, padding=1)
     if pool2 == 1: ref = F.avg_pool2d(ref, 2)
     elif pool2 == 2: ref = F.max_pool2d(ref, 2)
     if ms is not None: ref = ref * torch.where(ms.float() > 0, 1.0, 0.2)
@@ -61,8 +62,9 @@ for it in range(60):
         n = random.randint(1, 6); h = (8 if kind == "wide" else 16) * random.randint(1, 6); w = 32 * random.randint(1, 3)
         pool2 = random.choice([0, 0, 0, 1, 2]) if cout % 16 == 0 and cout > 32 and h % 16 == 0 else 0
     act = random.choice([0, 1, 2, 3] if pool2 == 0 else [0, 2]); res = random.choice([0, 0, 1, 2]) if pool2 != 2 else 0; mask = random.random() < 0.25 and pool2 == 0; bias = random.random() < 0.8
-    shape = (kind, n, cin, cout, h, w, act, res, mask, pool2, bias)
-    e = conv(n, cin, cout, h, w, act, res, mask, pool2, bias)
+    up = kind != "w16" and cout > 32 and pool2 == 0 and random.random() < 0.2
+    shape = (kind, n, cin, cout, h, w, act, res, mask, pool2, bias, up)
+    e = conv(n, cin, cout, h, w, act, res, mask, pool2, bias, up)
     note("conv3x3 " + kind, e, shape)
     if e > 8e-3: print("FAIL conv", shape, e, flush=True)
 for it in range(30):
