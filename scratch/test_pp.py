@@ -31,7 +31,7 @@ def check(n, cin, cout, hw, act=1, res=0, mask=False, pool2=0, up=False, bias=Tr
     torch.cuda.synchronize()
     ok = True
     for m in modes:
-        for prio in (1, 17):
+        for prio in tuple(int(a) for a in os.environ.get("PP_PRIOS", "1,17").split(",")):
             for rep in range(reps):
                 y1 = ops.nhwc_zeros(n, cout, ho, ho, dt, 'cuda')
                 setpp(m, prio)
@@ -82,7 +82,7 @@ if __name__ == "__main__":
     # ---- timing: interleaved rounds, old vs pp modes
     B = 20
     SHAPES = [(64, 64, 256), (128, 64, 128), (72, 64, 128), (128, 128, 128), (256, 256, 64), (512, 512, 32), (64, 128, 128), (128, 256, 64), (256, 512, 32), (256, 256, 32), (264, 256, 32), (136, 128, 64)]
-    variants = [("old", 0, -1)] + [("pp%d/p%d" % (m, pr), m, pr) for m in modes for pr in (1, 17)]
+    variants = [("old", 0, -1)] + [("pp%d/p%d" % (m, pr), m, pr) for m in modes for pr in tuple(int(a) for a in os.environ.get("PP_TPRIOS", "1,17").split(","))]
     tot = {v[0]: 0.0 for v in variants}
     for cin, cout, hw in SHAPES:
         x = ops.nhwc_empty(B, cin, hw, hw, dt, 'cuda'); x.normal_()
