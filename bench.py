@@ -461,7 +461,11 @@ def main():
                                   "memory-bound kernels, %s algorithmic GFLOP per image (necessary work, SURVEY.md 8d) x images/s per GPU"
                                   % (("%.2f" % gf) if gf else "n/a"),
                          "step_achieved": round(achieved, 2) if achieved else None,
-                         "step_frac": round(achieved / peak, 4) if achieved else None},
+                         "step_frac": round(achieved / peak, 4) if achieved else None,
+                         "sustained_mfma_peak": {"value": 2010.0, "unit": "TFLOP/s",
+                                                 "note": "recorded, not measured in this run: a registers-only v_mfma_f32_16x16x32_bf16 stream "
+                                                         "on every CU with random operands (scratch/mfma_rate.hip, profiles/README.md) - the "
+                                                         "power budget gives the matrix pipe 80 % of `peak`; frac stays priced on `peak`"}},
         }
         if world > 1:
             # what a bad scaling curve needs to be diagnosed: the collectives' own time, what of it was NOT hidden, each rank's pace
