@@ -256,7 +256,7 @@ class Job:
         images, labels, masks = synthetic.synthetic_batch(batch, 1234 + rank)
         images, labels, masks = images.to(dev), labels.to(dev), [m.to(dev) for m in masks]
         torch.manual_seed(100 + rank)                            # per-rank latent stream
-        mask_gen = torch.Generator(device=dev).manual_seed(7 + rank) if device_masks else None
+        mask_gen = torch.Generator().manual_seed(7 + rank) if device_masks else None     # CPU generator: one host draw per batch, no device sync
 
         def fresh_masks():
             return synthetic.training_masks_device(batch, dev, mask_gen) if device_masks else masks

@@ -383,7 +383,7 @@ inline int ew_grid(long items) { long b = (items + 255) / 256; return (int)(b > 
 // elementwise passes: blocks per sample so that a thread walks ~iters pixels (SP_TUNE_BN_ITERS)
 inline int apply_blocks(long hw, int c, int v, int n) {
     const int groups = c / v, lanes = groups < 256 ? groups : 256, pix_par = 256 / lanes;
-    const int iters = sp_tune(SP_TUNE_BN_ITERS, 2);      // 2 / 4 / 8 / 16 / 32 measured (scratch/bw_probe.py): 2 is at the rate of a device copy
+    const int iters = sp_tune(SP_TUNE_BN_ITERS, 2) < 1 ? 1 : sp_tune(SP_TUNE_BN_ITERS, 2);      // 2 / 4 / 8 / 16 / 32 measured (scratch/bw_probe.py): 2 is at the rate of a device copy
     long bx = (hw + (long)pix_par * iters - 1) / ((long)pix_par * iters);
     if (bx * n > 4096) bx = 4096 / n > 0 ? 4096 / n : 1;
     if (bx < 1) bx = 1;

@@ -346,6 +346,11 @@ class ModelWrapper(object):
         sig = self._batch_signature(images_real, labels, masks)
         st = self._graph_state
         if st is not None and st.get("flat_ptrs") != self._flat_ptrs():
+            if self._reducer_active():
+                # one rank replaying while another launches eagerly would pair different sequences of collectives (or hang); a
+                # re-allocation is deterministic program state, so it either happens on every rank or is a bug: fail loudly
+                raise RuntimeError("ModelWrapper.train(): the flat gradient buffers were re-allocated under a captured graph in a "
+                                   "data-parallel job - re-create the ModelWrapper on every rank")
             st = self._graph_state = None                       # gradient buffers re-allocated: eager steps, then a fresh capture
             self._eager_run = 0
         if st is not None and st.get("sig") == sig and st.get("w") == (w_rec, w_div):
@@ -363,7 +368,24 @@ class ModelWrapper(object):
                     self._graph_failed = True
                     import warnings
                     warnings.warn("ModelWrapper.train(): HIP-graph capture failed (%s); continuing with eager launches" % (exc,))
+                if self._reducer_active() and not self._ranks_agree(self._graph_state is not None):
+                    # data parallelism: every rank replays or none does (bench.py does the same) - the eager path hands its
+                    # gradient ranges over group by group, the replay path bucket by bucket: mixed ranks would mismatch
+                    self._graph_state = None
+                    self._graph_failed = True
         return out
+
+    def _reducer_active(self) -> bool:
+        return self.gradient_reducer is not None and self.gradient_reducer.active()
+
+    def _ranks_agree(self, ok: bool) -> bool:
+        """all-reduce(MIN) of a per-rank flag over the reducer's process group (one host sync, once per capture attempt)."""
+        import torch.distributed as dist
+        red = self.gradient_reducer
+        dev = next(self.generator.parameters()).device
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if dist.get_backend(red.group) == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=red.group)
+        return bool(int(flag.item()))
 
     def train(self, epochs: int = 20, validate_after_n_iterations: int = 100000, device: str = 'cuda',
               save_model_after_n_epochs: int = 1, w_rec: float = 0.1, w_div: float = 0.1) -> None:

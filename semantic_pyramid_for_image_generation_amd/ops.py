@@ -281,12 +281,18 @@ class SpectralNormBank:
 
     def _alloc_flat(self, device) -> None:
         self.flat = torch.zeros(self.flat_floats, dtype=torch.float32, device=device)
+        self._make_views()
+
+    def _make_views(self) -> None:
+        """The parameters' windows into `flat` for the CURRENT layout (grad_offs / bias_offs / extra_offs) and a fresh window
+        of passes.  Called for a new buffer and whenever a rebuild changed the layout under a retained buffer."""
         self.w_views = [self.flat[o:o + m.weight_orig.numel()].view(m.weight_orig.shape)
                         for o, (m, _, _) in zip(self.grad_offs, self.specs)]
         self.b_views = [self.flat[o:o + m.weight_orig.shape[0]] for o, (m, _, _) in zip(self.bias_offs, self.specs)]
         self.extra_views = [self.flat[o:o + p.numel()].view(p.shape) for o, p in zip(self.extra_offs, self.extra_params)]
         self.group_count = [0] * len(self.groups)
         self.win_touched, self.win_bias = set(), set()
+        self._view_layout = (tuple(self.grad_offs), tuple(self.bias_offs), tuple(self.extra_offs), len(self.groups))
 
     def enter_backward(self, device, group: int) -> None:
         """Start of a group's batched backward (direct mode).  The window continues iff the gradients this group assigned in the
@@ -425,6 +431,22 @@ class SpectralNormBank:
         # to replay graphs captured on the old one
         old_flat = getattr(self, "flat", None)
         self.flat = old_flat if (old_flat is not None and old_flat.numel() == flat_off and old_flat.device == torch.device(device)) else None
+        layout = (tuple(self.grad_offs), tuple(self.bias_offs), tuple(self.extra_offs), len(self.groups))
+        if self.flat is not None and getattr(self, "_view_layout", None) != layout:
+            # same size, other offsets (set_groups() changed the group count: the total is a sum of padded sizes, the per-layer
+            # offsets are not - round-3 ADVICE): the kernels will write at the NEW offsets, so the parameters' windows are rebuilt
+            # and every gradient still viewing the old ones is dropped (its contents are stale under the new layout anyway)
+            lo = self.flat.data_ptr()
+            hi = lo + 4 * self.flat.numel()
+            for m, _, _ in self.specs:
+                for p in m.parameters(recurse=False):
+                    if p.grad is not None and lo <= p.grad.data_ptr() < hi:
+                        p.grad = None
+            for p in self.extra_params:
+                if p.grad is not None and lo <= p.grad.data_ptr() < hi:
+                    p.grad = None
+            self.flat.zero_()
+            self._make_views()
         self.bwd_table_dev = torch.frombuffer(bytearray(bytes(btab)), dtype=torch.uint8).to(device)
 
     def begin(self, training: bool, dtype, device) -> SNCall:
@@ -1185,12 +1207,16 @@ class _DHeadFn(torch.autograd.Function):
         # gradients w.r.t. the normalised embedding / classifier go to the layers' arena slots (or to scratch if unused)
         demb_sn = pl_emb.call.dw_slot(pl_emb) if need[1] else torch.empty(pl_emb.rows * pl_emb.cols, dtype=torch.float32, device=dev)
         dwc_sn = pl_cls.call.dw_slot(pl_cls) if need[2] else torch.empty(f, dtype=torch.float32, device=dev)
-        dbc = torch.empty(1, dtype=torch.float32, device=dev)
+        # direct mode: the classification bias gradient goes to the layer's bias slot of the arena, so the batched spectral-norm
+        # backward moves it into the flat buffer BEFORE the group's on_group_done hook hands that range to the reducer (round-3
+        # ADVICE: returned through autograd it reached `flat` only after .backward(), i.e. after the range had been all-reduced)
+        slot_bias = need[2] and need[3] and pl_cls.call.bank.direct_grads
+        dbc = pl_cls.call.db_slot(pl_cls) if slot_bias else torch.empty(1, dtype=torch.float32, device=dev)
         sdp = torch.empty(b, dtype=torch.float32, device=dev)             # per-sample sums between the call's two kernels
         L.call("sp_dhead_bwd", ptr(dpred), ptr(x), x.stride(0), ctypes.c_void_p(pl_emb.fwd), ptr(cls), ctypes.c_void_p(pl_cls.fwd),
                ptr(dx), dx.stride(0), ptr(demb_sn), pl_emb.rows, ptr(dwc_sn), ptr(dbc), ptr(sdp), b, f, sp_dtype(x.dtype), stream())
         z = _zero1(dev)
-        return dx, (z if need[1] else None), (z if need[2] else None), (dbc if need[3] else None), None, None, None
+        return dx, (z if need[1] else None), (z if need[2] else None), (dbc if need[3] and not slot_bias else None), None, None, None
 
 
 def discriminator_head(x, emb_module, cls_module, cls_idx):

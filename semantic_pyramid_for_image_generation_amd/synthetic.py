@@ -65,9 +65,6 @@ def training_masks(g: torch.Generator, p_random_mask: float = 0.3) -> List[torch
     return masks_for_stage(stage, spatial)
 
 
-_MASK_STEP = {}
-
-
 def training_masks_device(batch_size: int, device, generator: Optional[torch.Generator] = None,
                           p_random_mask: float = 0.3, seed: Optional[int] = None) -> List[torch.Tensor]:
     """A whole batch of training masks generated ON THE DEVICE by one kernel launch (sp_training_masks): the
@@ -75,8 +72,10 @@ def training_masks_device(batch_size: int, device, generator: Optional[torch.Gen
     Same contract as training_masks(): stage ~ choice([0..6, 0, 1]) counted from the deep end; with probability p_random_mask
     and 0 < stage < 6 a 0/1 map of 1-4 zero rectangles at the level just finer than the stage is nearest-upsampled to all finer
     levels; everything deeper than the stage is zero; values are exact 0.0 / 1.0.  ``seed``: the 64-bit seed of this batch
-    (the generator is counter based: no device RNG state, no host sync); without it the seed is ``generator.initial_seed()``
-    (or 0) plus a per-generator call counter."""
+    (the kernel is counter based: no device RNG state, no host sync).  Without it one 63-bit draw is taken from ``generator``
+    (a CPU generator: no device sync; re-seeding it restarts the mask sequence, and its state travels with it - round-3 ADVICE:
+    a module-level counter keyed by id(generator) did neither); without a generator, from torch's default CPU generator mixed with
+    the process's RANK, so that the ranks of a data-parallel job draw different masks."""
     import ctypes
     from . import _lib as L
     from . import ops
@@ -84,11 +83,12 @@ def training_masks_device(batch_size: int, device, generator: Optional[torch.Gen
     if dev.type != "cuda":
         raise L.SempyrError("training_masks_device: needs a CUDA/HIP device (no CPU path; tests use the oracle's restatement)")
     if seed is None:
-        key = id(generator) if generator is not None else 0
-        base = int(generator.initial_seed()) if generator is not None else 0
-        step = _MASK_STEP.get(key, 0)
-        _MASK_STEP[key] = step + 1
-        seed = (base * 0x9E3779B97F4A7C15 + step) & ((1 << 64) - 1)
+        import os
+        if generator is not None and generator.device.type != "cpu":
+            raise L.SempyrError("training_masks_device: pass a CPU torch.Generator (a device generator would cost a host sync per batch)")
+        draw = int(torch.randint(0, (1 << 63) - 1, (1,), dtype=torch.int64, generator=generator))
+        rank = int(os.environ.get("RANK", "0")) if generator is None else 0
+        seed = (draw + rank * 0x9E3779B97F4A7C15) & ((1 << 64) - 1)
     out = [torch.empty((batch_size,) + shp, dtype=torch.float32, device=dev) for shp in MASK_SHAPES]
     L.call("sp_training_masks", *[ops.ptr(t) for t in out], batch_size, ctypes.c_uint64(seed), float(p_random_mask), ops.stream())
     return out

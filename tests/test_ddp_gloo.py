@@ -137,6 +137,38 @@ def test_bank_rebuild_keeps_the_flat_gradient_buffer():
     assert bank.flat is not None and bank.flat.data_ptr() == ptr and bank.flat_floats == floats
 
 
+def test_bank_regroup_rebuilds_the_gradient_windows():
+    """set_groups() changes the per-layer offsets inside a flat buffer of the SAME size (round-3 ADVICE): the retained buffer's
+    parameter windows, group counters and stale .grad views must follow the new table, in both directions (4 -> 1, 1 -> 4)."""
+    import semantic_pyramid_for_image_generation_amd as sp
+    from semantic_pyramid_for_image_generation_amd import _lib as L
+    import ctypes
+    net = sp.Discriminator(channel_factor=8)
+    bank = net._bank
+
+    def table_offsets():
+        raw = bytes(bank.bwd_table_dev.numpy().tobytes())
+        tab = (L.SpSnBwdLayer * len(bank.specs)).from_buffer_copy(raw)
+        return [int(t.grad_off) for t in tab], [int(t.bias_off) for t in tab]
+    bank.set_groups(4)
+    bank._build(torch.float32, "cpu")
+    bank._alloc_flat("cpu")
+    ptr = bank.flat.data_ptr()
+    probe = bank.specs[3][0].weight_orig
+    probe.grad = bank.w_views[3]                          # a gradient left over from the old layout
+    for groups in (1, 4, 1):
+        bank.set_groups(groups)
+        bank._build(torch.float32, "cpu")
+        assert bank.flat.data_ptr() == ptr and len(bank.group_count) == groups == len(bank.groups)
+        g_off, b_off = table_offsets()
+        for i, (m, _, _) in enumerate(bank.specs):
+            assert bank.w_views[i].data_ptr() == ptr + 4 * g_off[i], (groups, i)
+            assert bank.b_views[i].data_ptr() == ptr + 4 * b_off[i], (groups, i)
+        assert probe.grad is None or probe.grad.data_ptr() == bank.w_views[3].data_ptr()
+        probe.grad = bank.w_views[3]
+        bank.enter_backward(torch.device("cpu"), groups - 1)      # used to raise IndexError after 1 -> 4
+
+
 def test_bench_spawns_its_own_ranks():
     """bench.py --gpus N without an outer launcher: N children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set and
     rendezvous on 127.0.0.1; the parent (which never touches the GPU) relays rank 0's output and the worst exit code."""

@@ -44,8 +44,13 @@ def test_device_mask_generation_contract_and_step():
     """Row f1: synthetic.training_masks_device() on the GPU keeps the a15 contract (exact 0/1 values, one open stage per
     sample counted from the deep end, finer levels = nearest-neighbour copies of one rectangle map, deeper levels zero) and
     its output drives a training step directly - no host round trip."""
-    g = torch.Generator(device="cuda").manual_seed(3)
+    g = torch.Generator().manual_seed(3)
     masks = synthetic.training_masks_device(256, "cuda", g)
+    # the sequence belongs to the generator: re-seeding restarts it, and two consecutive batches differ (round-3 ADVICE)
+    again = synthetic.training_masks_device(256, "cuda", torch.Generator().manual_seed(3))
+    assert all(torch.equal(a, b) for a, b in zip(masks, again))
+    nxt = synthetic.training_masks_device(256, "cuda", g)
+    assert any(not torch.equal(a, b) for a, b in zip(masks, nxt))
     shapes = [(1, 128, 128), (1, 64, 64), (1, 32, 32), (1, 16, 16), (1, 8, 8), (4096,), (365,)]
     assert all(m.is_cuda and m.dtype == torch.float32 for m in masks)
     assert [tuple(t.shape[1:]) for t in masks] == shapes
@@ -182,6 +187,69 @@ def test_every_gradient_lives_in_the_flat_buffer():
     fake, z = mw._g_forward(images, labels.float(), masks, feats, None)
     mw._g_rest(fake, z, labels, masks, feats, 0.1, 0.1)
     assert inside(G, "g") == ([], []), inside(G, "g")
+
+
+class _HalvingReducer:
+    """Stands in for an all-reduce whose result DIFFERS from the rank's own gradients (what a second rank with other data causes):
+    every range handed over is halved in place on the current stream, exactly once."""
+    bucket_bytes = 1 << 20
+
+    def __init__(self):
+        self.ranges = []
+
+    def active(self):
+        return True
+
+    def reduce_range(self, flat, a, b):
+        self.ranges.append((a, b))
+        flat[a:b].mul_(0.5)
+
+    def reduce_flat(self, flat, ranges):
+        for a, b in ranges:
+            self.reduce_range(flat, a, b)
+
+    def reduce(self, params):
+        raise AssertionError("a gradient outside the flat buffer reached the per-parameter path")
+
+    def join(self, tag=""):
+        pass
+
+
+def test_eager_group_hooks_reduce_every_gradient_exactly_once():
+    """Round-3 ADVICE (medium): on the eager data-parallel path the bank's layer groups hand their flat range to the reducer from
+    INSIDE the backward pass.  A gradient that reaches the flat buffer only after .backward() returned (the discriminator head's
+    classification bias used to) is then skipped as 'already reduced' - un-averaged on N > 1 ranks - and its late copy races with
+    the collective.  With a reducer whose result differs from the local gradients (it halves every range it is given), every
+    gradient of D and of G must come out at exactly half of the reducer-less run."""
+    ops.set_compute_dtype(torch.float32)
+    images, labels, masks = gu.golden_batches(4, 1)[0]
+    images, labels, masks = images.cuda(), labels.cuda(), [m.cuda() for m in masks]
+    noise = torch.randn(2, 4, 128, generator=torch.Generator().manual_seed(5)).cuda()
+
+    def run(reducer):
+        G, D, V = build(4, 1)
+        og, od = sp.optim.Adam(G.parameters(), lr=1e-4), sp.optim.Adam(D.parameters(), lr=1e-4)
+        mw = sp.ModelWrapper(generator=G, discriminator=D, vgg16=V, training_dataset=None, validation_dataset=None,
+                             generator_optimizer=og, discriminator_optimizer=od, save_data_path=None, gradient_reducer=reducer)
+        G.train(); D.train()
+        feats, _, _ = mw._d_phase(images, labels, labels.float(), masks, noise[0])
+        mw._start_reduce("d", mw._d_params, eager=True)
+        dg = {n: p.grad.detach().clone() for n, p in D.named_parameters()}
+        fake, z = mw._g_forward(images, labels.float(), masks, feats, noise[1])
+        mw._g_rest(fake, z, labels, masks, feats, 0.1, 0.1)
+        mw._start_reduce("g", mw._g_params, eager=True)
+        gg = {n: p.grad.detach().clone() for n, p in G.named_parameters()}
+        torch.cuda.synchronize()
+        return dg, gg
+
+    ref_d, ref_g = run(None)
+    red = _HalvingReducer()
+    got_d, got_g = run(red)
+    assert len(red.ranges) > 8
+    assert float(ref_d["classification.bias"].abs().sum()) > 0.0
+    for ref, got, tag in ((ref_d, got_d, "D"), (ref_g, got_g, "G")):
+        for n in ref:
+            assert torch.equal(got[n], ref[n] * 0.5), (tag, n)
 
 
 def test_multi_gpu_code_path_in_a_one_rank_rccl_group():
