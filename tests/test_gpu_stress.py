@@ -180,6 +180,8 @@ def test_batch_norm_and_bilinear_random_shapes(dtype, tol):
         n = random.randint(1, 6)
         h, w = random.choice([1, 2, 4, 7, 8, 16, 30, 32, 64]), random.choice([1, 2, 4, 8, 9, 16, 32, 48, 64])
         act, cond, fuse_up = random.choice([0, 1]), random.random() < 0.4, random.random() < 0.3
+        if n * h * w < 4:                # a channel with 1-3 samples: variance ~ 0, the gradient is 0/0-conditioned in any arithmetic
+            continue
         x0 = torch.randn(n, c, h, w, device='cuda').to(dtype).float()
         gy = torch.randn(n, c, h * (2 if fuse_up else 1), w * (2 if fuse_up else 1), device='cuda').to(dtype).float()
         emb = torch.randn(7, 2 * c, device='cuda') if cond else None
