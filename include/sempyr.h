@@ -80,6 +80,9 @@ enum { SP_TUNE_CONV_TALL = 0, SP_TUNE_IGEMM_DMA = 1, SP_TUNE_WGRAD_ROWS = 2, SP_
        SP_TUNE_CONV_STAGGER = 16, SP_TUNE_CONV1X1_SPLITK = 17, SP_TUNE_WGRAD1X1 = 18, SP_TUNE_CONV_CIN8 = 19, SP_TUNE_CONV_THINCO = 20, SP_TUNE_CONV_PP = 21, SP_TUNE_CONV_PP_PRIO = 22, SP_TUNE_WGRAD_PP = 23, SP_TUNE_BN_ITERS = 24, SP_TUNE_COUNT = 25 };
 int sp_set_tuning(int32_t key, int32_t value);
 const char* sp_last_error_string(void);
+/* Name of the kernel (route) the last sp_conv2d_igemm / sp_conv2d_wgrad* call of THIS thread launched ("" before the first one):
+ * lets a profiler-less caller attribute its event timings to kernels (bench.py's per-route table).  Static strings. */
+const char* sp_last_route(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Convolution as NHWC implicit GEMM on MFMA (3x3 stride 1 pad 1, or 1x1).

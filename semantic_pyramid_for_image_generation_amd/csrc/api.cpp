@@ -14,6 +14,10 @@ extern "C" void sp_set_error(const char* fmt, ...) {
 extern "C" const char* sp_last_error_string(void) { return g_err; }
 extern "C" int sp_version(void) { return SP_VERSION; }
 
+static thread_local const char* g_route = "";
+extern "C" void sp_note_route(const char* name) { g_route = name; }
+extern "C" const char* sp_last_route(void) { return g_route; }
+
 // knobs for tests and A/B runs (-1 = built-in default); the library itself never reads the environment
 struct SpTuneInit { int v[SP_TUNE_COUNT]; SpTuneInit() { for (int i = 0; i < SP_TUNE_COUNT; ++i) v[i] = -1; } };
 static SpTuneInit g_tune_init;

@@ -106,6 +106,8 @@ __device__ __forceinline__ void apply_act_vec(float (&v)[N], int act) {
 
 // ---- host-side error plumbing (defined in api.cpp) -----------------------------------------
 extern "C" void sp_set_error(const char* fmt, ...);
+// the kernel a conv / weight-gradient entry point chose for its last launch on this thread (sp_last_route, bench.py's table)
+extern "C" void sp_note_route(const char* name);
 #define SP_CHECK_ARG(cond, ...) do { if (!(cond)) { sp_set_error(__VA_ARGS__); return SP_ERR_INVALID; } } while (0)
 #define SP_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { \
     sp_set_error("%s:%d HIP launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); return SP_ERR_LAUNCH; } } while (0)

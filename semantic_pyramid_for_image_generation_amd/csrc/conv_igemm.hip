@@ -434,6 +434,7 @@ int launch_halo(const sp_conv_params& p, hipStream_t s) {
         attr_set = true;
     }
     dim3 grid((unsigned)(p.n * (p.h / HALO_TH) * (p.w_ / HALO_TW) * ((p.cout + CO_T - 1) / CO_T)));
+    sp_note_route(sizeof(T) == 4 ? "conv3x3_halo<f32>" : "conv3x3_halo<16bit>");
     hipLaunchKernelGGL(kern, grid, dim3(CO_T * 4), LDS, s, p);
     SP_LAUNCH_CHECK();
     return SP_OK;
@@ -1017,6 +1018,8 @@ int launch_tall(const sp_conv_params& p, hipStream_t s) {
     int grid = total < g_num_cu ? total : g_num_cu;        // persistent: one block per CU
     if (grid >= 8) grid -= grid % 8;
     // measured (scratch/ab_conv.py, profiles/README.md): staggering helps the 16-row 128-co tile (+3-5 %) and costs the 8-row one 4 %
+    sp_note_route(sizeof(T) == 4 ? (WCO == 1 ? "conv3x3_tall<f32,1,16>" : TH == 16 ? "conv3x3_tall<f32,2,16>" : "conv3x3_tall<f32,2,8>")
+                                 : (WCO == 1 ? "conv3x3_tall<16bit,1,16>" : TH == 16 ? "conv3x3_tall<16bit,2,16>" : "conv3x3_tall<16bit,2,8>"));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), LDS, s, p, cotiles, total, sp_tune(SP_TUNE_CONV_STAGGER, (WCO == 2 && TH == 16) ? 1 : 0));
     SP_LAUNCH_CHECK();
     return SP_OK;
@@ -1060,6 +1063,7 @@ int launch_dma(const sp_conv_params& p, hipStream_t s) {
         ksplit = (nk + per - 1) / per;                 // every split owns at least one K-step, so every slab is fully written
     }
     dim3 grid((unsigned)((M + PX_T - 1) / PX_T), (unsigned)((p.cout + CO_T - 1) / CO_T), (unsigned)ksplit);
+    sp_note_route(ksplit > 1 ? "conv_igemm_dma+finalize (split-K)" : "conv_igemm_dma");
     hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, p, ksplit);
     SP_LAUNCH_CHECK();
     if (ksplit > 1) {
@@ -1084,6 +1088,7 @@ int launch_cfg(const sp_conv_params& p, hipStream_t s) {
     }
     const long M = (long)p.n * p.h * p.w_;
     dim3 grid((unsigned)((M + PX_T - 1) / PX_T), (unsigned)((p.cout + CO_T - 1) / CO_T));
+    sp_note_route("conv_igemm (register-staged)");
     hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, p);
     SP_LAUNCH_CHECK();
     return SP_OK;
@@ -1186,6 +1191,7 @@ int launch_1x1_direct(const sp_conv_params& p, hipStream_t s) {
     long gx = (M + 127) / 128;                                           // one 32-pixel group per wave and pass at most
     const long cap = 1024 / cotiles > 0 ? 1024 / cotiles : 1;
     if (gx > cap) gx = cap;
+    sp_note_route("conv1x1_direct");
     hipLaunchKernelGGL(conv1x1_direct_kernel, dim3((unsigned)gx, (unsigned)cotiles), dim3(256), lds, s, p, row_bytes);
     SP_LAUNCH_CHECK();
     return SP_OK;
@@ -1279,6 +1285,7 @@ int launch_1x1_splitk(const sp_conv_params& p, hipStream_t s) {
     const int ksteps = (p.cin_p + 31) / 32;
     const long M = (long)p.n * p.h * p.w_;
     dim3 grid((unsigned)((M + 31) / 32), (unsigned)((p.cout + 63) / 64));
+    sp_note_route("conv1x1_splitk");
     if (ksteps <= 8) hipLaunchKernelGGL(conv1x1_splitk_kernel<2>, grid, dim3(256), 0, s, p);
     else if (ksteps <= 16) hipLaunchKernelGGL(conv1x1_splitk_kernel<4>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(conv1x1_splitk_kernel<6>, grid, dim3(256), 0, s, p);
@@ -1384,6 +1391,7 @@ __global__ __launch_bounds__(256) void conv3x3_cin8_kernel(sp_conv_params p) {
 
 int launch_cin8(const sp_conv_params& p, hipStream_t s) {
     const long blocks = (long)p.n * (p.h / C8_TH) * (p.w_ / C8_TW);
+    sp_note_route("conv3x3_cin8");
     hipLaunchKernelGGL(conv3x3_cin8_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
     SP_LAUNCH_CHECK();
     return SP_OK;
@@ -1479,6 +1487,7 @@ int launch_thinco(const sp_conv_params& p, hipStream_t s) {
         attr_set = true;
     }
     const long blocks = (long)p.n * (p.h / TN_TH) * (p.w_ / TN_TW);
+    sp_note_route("conv3x3_thinco");
     hipLaunchKernelGGL(conv3x3_thinco_kernel<KC>, dim3((unsigned)blocks), dim3(256), LDS, s, p);
     SP_LAUNCH_CHECK();
     return SP_OK;

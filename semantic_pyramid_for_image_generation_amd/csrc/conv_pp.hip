@@ -612,6 +612,8 @@ int launch_pp(const sp_conv_params& p, int prio, hipStream_t s) {
     const int total = p.n * (p.h / TH) * (p.w_ / G::TW) * cotiles;
     int grid = total < PP_NUM_CU ? total : PP_NUM_CU;       // persistent: one block per CU
     if (grid >= 8) grid -= grid % 8;
+    sp_note_route(G::F8 ? "conv3x3_pp<f8,2>" : FW == 1 ? "conv3x3_pp<16bit,2,FAST,w16>" : WCO == 2 ? (FAST ? "conv3x3_pp<16bit,2,FAST>" : "conv3x3_pp<16bit,2>")
+                                                                                  : (FAST ? "conv3x3_pp<16bit,1,FAST>" : "conv3x3_pp<16bit,1>"));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), G::LDS, s, p, cotiles, total, prio);
     SP_LAUNCH_CHECK();
     return SP_OK;

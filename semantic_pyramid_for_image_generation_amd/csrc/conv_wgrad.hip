@@ -616,6 +616,7 @@ int launch_wgrad9(const T* x, const T* dy, float* dw, int n, int h, int w, int c
     }
     const long n_dw = (long)cout * 9 * cin;
     dim3 grid(sp_div_up(cin, 64), sp_div_up(cout, 64), (unsigned)pl.nsplit);
+    sp_note_route("conv_wgrad9 (per-tap, <= 64 channels)");
     hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, x, dy, dw, n, h, w, cin, cout, ld_dy, (int)pl.per_split, dbias, w_packed, dot, slabs, n_dw,
                        bias_slabs, bias_ld);
     SP_LAUNCH_CHECK();
@@ -638,6 +639,7 @@ int launch_wgrad(const T* x, const T* dy, float* dw, int n, int h, int w, int ci
     const int taps = ksize * ksize;
     const long n_dw = (long)cout * taps * cin;
     dim3 grid(sp_div_up(cin, CI_T), sp_div_up(cout, CO_T), taps * pl.nsplit);
+    sp_note_route(sizeof(T) == 4 ? "conv_wgrad<f32> (per-tap)" : "conv_wgrad<16bit> (per-tap)");
     hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, x, dy, dw, n, h, w, cin, cout, ld_dy, ksize, pl.nsplit, pl.per_split, dbias, w_packed, dot,
                        slabs, n_dw, bias_slabs, bias_ld);
     SP_LAUNCH_CHECK();

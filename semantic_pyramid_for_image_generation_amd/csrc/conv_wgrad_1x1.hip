@@ -432,6 +432,7 @@ int sp_wgrad1x1_launch(const void* x, const void* dy, float* dw, float* dbias, i
         if (e != hipSuccess) { sp_set_error("hipFuncSetAttribute(LDS=%d) failed: %s", W1_LDS, hipGetErrorString(e)); return SP_ERR_LAUNCH; }
         attr_set = true;
     }
+    sp_note_route("wgrad1x1_stream + reduce");
     hipLaunchKernelGGL(wgrad1x1_stream_kernel, dim3((unsigned)(p.tiles * (p.nsplit >= 8 ? ((p.nsplit + 7) / 8) * 8 : p.nsplit))), dim3(256), W1_LDS, s, a);
     SP_LAUNCH_CHECK();
     if (p.nsplit > 1) {
@@ -501,6 +502,7 @@ int sp_wgrad3x3_cin8_launch(const void* x, const void* dy, float* dw, float* dbi
     int logw = 0, logh = 0;
     while ((1 << logw) < w) ++logw;
     while ((1 << logh) < h) ++logh;
+    sp_note_route("wgrad3x3_cin8_stream + reduce");
     hipLaunchKernelGGL(wgrad3x3_cin8_stream_kernel, dim3((unsigned)(p.tiles * (p.nsplit >= 8 ? ((p.nsplit + 7) / 8) * 8 : p.nsplit))), dim3(256), C8_LDS, s, a,
                        h, w, logw, logh);
     SP_LAUNCH_CHECK();

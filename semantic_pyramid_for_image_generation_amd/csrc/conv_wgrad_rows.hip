@@ -1110,6 +1110,7 @@ int sp_wgrad_rows_launch(const void* x, const void* dy, float* dw, float* dbias,
         a.slabs = use_slabs && (long)nb * pairs <= 512 ? ws : nullptr;
         a.bias_part = (a.slabs != nullptr && dbias != nullptr) ? ws + 512L * 9 * 64 * 64 : nullptr;
         a.thin_mode = 0;
+        sp_note_route("conv_wgrad_pp3 (row walker, ping-pong) + rows_reduce");
         if (sp_tune(SP_TUNE_WGRAD_PP, 1) == 2) hipLaunchKernelGGL(conv_wgrad_pp_kernel, dim3((unsigned)nb, (unsigned)pairs), dim3(512), WP_LDS, s, a, rpb, rows_total);
         else if (sp_tune(SP_TUNE_WGRAD_PP, 1) == 3) { a.thin_mode = sp_tune(SP_TUNE_WGRAD_ROWS_THIN, 0); hipLaunchKernelGGL(conv_wgrad_pp3_kernel<true>, dim3((unsigned)nb, (unsigned)pairs), dim3(512), WP3_LDS, s, a, rpb, rows_total); SP_LAUNCH_CHECK(); return SP_OK; }
         else hipLaunchKernelGGL(conv_wgrad_pp3_kernel<false>, dim3((unsigned)nb, (unsigned)pairs), dim3(512), WP3_LDS, s, a, rpb, rows_total);
@@ -1135,6 +1136,7 @@ int sp_wgrad_rows_launch(const void* x, const void* dy, float* dw, float* dbias,
     }
     a.slabs = use_slabs && (long)nblk * pairs <= 512 ? ws : nullptr;
     a.bias_part = (a.slabs != nullptr && dbias != nullptr) ? ws + 512L * 9 * 64 * 64 : nullptr;
+    sp_note_route(nw == 16 ? "conv_wgrad_rows<16> + rows_reduce" : nw == 8 ? "conv_wgrad_rows<8> + rows_reduce" : "conv_wgrad_rows<0> + rows_reduce");
     if (nw == 16) hipLaunchKernelGGL(conv_wgrad_rows_kernel<16>, dim3((unsigned)nblk, (unsigned)pairs), dim3(256), WR_LDS, s, a);
     else if (nw == 8) hipLaunchKernelGGL(conv_wgrad_rows_kernel<8>, dim3((unsigned)nblk, (unsigned)pairs), dim3(256), WR_LDS, s, a);
     else hipLaunchKernelGGL(conv_wgrad_rows_kernel<0>, dim3((unsigned)nblk, (unsigned)pairs), dim3(256), WR_LDS, s, a);

@@ -513,12 +513,13 @@ def packed_layer(module, training: bool, dtype, device) -> PackedLayer:
 KERNEL_PROBE = None
 
 
-def _probed(family: str, flops: float, dominant: bool, fn) -> None:
+def _probed(family: str, flops: float, dominant: bool, fn, shape=None) -> None:
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     fn()
     e1.record()
-    KERNEL_PROBE.append((e0, e1, flops, family, dominant))
+    route = L.lib().sp_last_route().decode()          # the kernel the entry point chose (include/sempyr.h: sp_last_route)
+    KERNEL_PROBE.append((e0, e1, flops, family, dominant, route, shape))
 
 
 def _is_halo128(n, h, w, cout, ksize) -> bool:
@@ -550,7 +551,8 @@ def conv_launch(x, w_ptr: int, bias, y, res1, res2, mask_src, slope: float, n, h
                 dtype, pool2: bool = False, in_up2: bool = False, family: str = "fwd") -> None:
     if KERNEL_PROBE is not None:
         _probed(family, 2.0 * n * h * w * cin_p * cout * ksize * ksize, _is_halo128(n, h, w, cout, ksize),
-                lambda: _conv_launch(x, w_ptr, bias, y, res1, res2, mask_src, slope, n, h, w, cin_p, cout, ldy, ksize, act, dtype, pool2, in_up2))
+                lambda: _conv_launch(x, w_ptr, bias, y, res1, res2, mask_src, slope, n, h, w, cin_p, cout, ldy, ksize, act, dtype, pool2, in_up2),
+                (ksize, cin_p, cout, h, w, n))
         return
     _conv_launch(x, w_ptr, bias, y, res1, res2, mask_src, slope, n, h, w, cin_p, cout, ldy, ksize, act, dtype, pool2, in_up2)
 
@@ -688,7 +690,7 @@ class _ConvFn(torch.autograd.Function):
                 L.call("sp_conv2d_wgrad_accum_pooled" if up2 else "sp_conv2d_wgrad_accum", ptr(x), ptr(dz), ptr(dwsn), ptr(db), ptr(ws),
                        ws_floats, n, h, w, cin_p, cout, cout_p, ksize, sp_dtype(dt), stream())
             if KERNEL_PROBE is not None:
-                _probed("wgrad", 2.0 * n * h * w * cin_p * cout * ksize * ksize, False, launch_wgrad)
+                _probed("wgrad", 2.0 * n * h * w * cin_p * cout * ksize * ksize, False, launch_wgrad, (ksize, cin_p, cout, h, w, n))
             else:
                 launch_wgrad()
             dh = _zero1(x.device)
@@ -1380,6 +1382,6 @@ def conv_launch_f8(x8: torch.Tensor, w8: torch.Tensor, w_scale: torch.Tensor, x_
     p.y8_inv_scale = y8_inv_scale.data_ptr() if y8_inv_scale is not None else None
     p.y8_amax = y8_amax.data_ptr() if y8_amax is not None else None
     if KERNEL_PROBE is not None:
-        _probed("fwd", 2.0 * n * h * w * cin_p * cout * 9, False, lambda: L.call("sp_conv2d_igemm", ctypes.byref(p), stream()))
+        _probed("fwd", 2.0 * n * h * w * cin_p * cout * 9, False, lambda: L.call("sp_conv2d_igemm", ctypes.byref(p), stream()), (3, cin_p, cout, h, w, n))
         return
     L.call("sp_conv2d_igemm", ctypes.byref(p), stream())
