@@ -128,6 +128,16 @@ typedef struct sp_conv_params {
     void* y8;               /* e4m3 output or NULL                                   (SP_F8 only) */
     const float* y8_inv_scale; /* [1] quantisation scale of y8 (1 / its dequantisation scale), required with y8 */
     float* y8_amax;         /* [1] running max of v, or NULL                         (SP_F8 only) */
+    /* Two-group batch (SP_F32 / SP_BF16): img_scale != NULL multiplies the fp32 accumulator of image n by img_scale[n >= img_split]
+     * BEFORE bias / mask / residuals / activation:  y = act((conv(x, w) * img_scale[g(n)] + bias) * slope(mask_src) + res1 + res2).
+     * It lets the discriminator's D(real) and D(fake) passes of one step (model_wrapper.py:153-155) - same weight_orig, but a
+     * different spectral-norm sigma each, since every forward advances the power iteration (models.py:128-135) - run as ONE launch
+     * over 2B images with the packing W / sigma_real and img_scale = {1, sigma_real / sigma_fake}; the same launch form computes the
+     * input gradient (dgrad packing).  DEVICE pointer to 2 floats, both > 0.  NULL: no scaling (img_split ignored). */
+    const float* img_scale;
+    int32_t img_split;      /* images [0, img_split) use img_scale[0], the rest img_scale[1] */
+    int32_t reserved_;
+    int64_t split_pix_;     /* set by the library (first OUTPUT pixel index of the second group); callers leave it 0 */
 } sp_conv_params;
 int sp_conv2d_igemm(const sp_conv_params* p, sp_stream_t stream);
 /* Bytes of fp32 scratch sp_conv2d_igemm wants in sp_conv_params.workspace to split the K loop of this shape over several
@@ -213,6 +223,12 @@ typedef struct sp_sn_layer {
 int sp_sn_forward(const sp_sn_layer* table_dev, int32_t n_layers, int32_t max_rows, int32_t max_cols,
                   int64_t max_pack_elems, float* scratch, int64_t scratch_floats, void* pack_arena,
                   int32_t power_iter, int32_t dtype, int32_t pack_blocks, sp_stream_t stream);
+/* Two forwards of one network whose activations run as ONE two-group batch (sp_conv_params.img_scale; the discriminator's
+ * D(real) / D(fake), model_wrapper.py:153-155): forward a packed W / sigma_a, forward b (one more power iteration) has sigma_b.
+ * out[2 i] = 1, out[2 i + 1] = sigma_a / sigma_b for layer i - the per-group accumulator scales of a launch that uses a's
+ * packing.  scratch_a / scratch_b: the scratch buffers of the two sp_sn_forward calls (same table). */
+int sp_sn_pair_scales(const sp_sn_layer* table_dev, int32_t n_layers, const float* scratch_a, const float* scratch_b, float* out,
+                      sp_stream_t stream);
 /* The same backward for every layer of a network in one call (two launches).  Offsets are in floats: dw_off / dot_off
  * into `arena` (the caller zero-fills the arena once per backward pass; the weight-gradient kernels accumulate the
  * dW slots, this call the dots), scratch_off into the scratch of the matching sp_sn_forward call, grad_off into

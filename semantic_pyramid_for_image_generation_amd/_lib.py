@@ -37,7 +37,9 @@ class SpConvParams(ctypes.Structure):
                 ("dtype", ctypes.c_int32), ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64),
                 ("pool2", ctypes.c_int32), ("in_up2", ctypes.c_int32),
                 ("x_scale", ctypes.c_void_p), ("w_scale", ctypes.c_void_p), ("y8", ctypes.c_void_p),
-                ("y8_inv_scale", ctypes.c_void_p), ("y8_amax", ctypes.c_void_p)]
+                ("y8_inv_scale", ctypes.c_void_p), ("y8_amax", ctypes.c_void_p),
+                ("img_scale", ctypes.c_void_p), ("img_split", ctypes.c_int32), ("reserved_", ctypes.c_int32),
+                ("split_pix_", ctypes.c_int64)]
 
 
 class SpSnLayer(ctypes.Structure):

@@ -40,8 +40,17 @@ __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>
 template <int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
+// two-group batches (sp_conv_params.img_scale): the scale of the group output pixel `pix` belongs to (pix counts OUTPUT pixels)
+__device__ __forceinline__ float conv_img_scale(const sp_conv_params& p, long pix) {
+    return p.img_scale != nullptr ? p.img_scale[pix >= p.split_pix_ ? 1 : 0] : 1.f;
+}
+
 template <typename T>
 __device__ __forceinline__ void conv_epilogue4(const sp_conv_params& p, float (&v)[4], long pix, int co, bool vec_ok, bool add_bias = true) {
+    if (p.img_scale != nullptr && add_bias) {      // (add_bias == false: the caller pre-added the bias and has applied the scale itself)
+        const float sc = conv_img_scale(p, pix);
+        v[0] *= sc; v[1] *= sc; v[2] *= sc; v[3] *= sc;
+    }
     T* __restrict__ yg = reinterpret_cast<T*>(p.y);
     const T* r1 = reinterpret_cast<const T*>(p.res1);
     const T* r2 = reinterpret_cast<const T*>(p.res2);
@@ -135,6 +144,11 @@ __device__ __forceinline__ void conv_epilogue16_values(const sp_conv_params& p, 
 template <typename T>
 __device__ __forceinline__ void conv_epilogue16(const sp_conv_params& p, float (&v)[16], long pix, int co, bool add_bias = true) {
     const long off = pix * p.ldy + co;
+    if (p.img_scale != nullptr && add_bias) {
+        const float sc = conv_img_scale(p, pix);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] *= sc;
+    }
     conv_epilogue16_values<T>(p, v, off, co, add_bias);
     Wide16<T>::st(reinterpret_cast<T*>(p.y) + off, v);
 }

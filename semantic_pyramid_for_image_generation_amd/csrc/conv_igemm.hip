@@ -168,6 +168,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(sp_conv_params p) {
             if (co >= p.cout) continue;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             const long off = pix * p.ldy + co;
+            if (p.img_scale != nullptr) {
+                const float sc = conv_img_scale(p, pix);
+                v[0] *= sc; v[1] *= sc; v[2] *= sc; v[3] *= sc;
+            }
             if (vec_ok) {
                 if (p.bias) {
                     const float4 bv = *reinterpret_cast<const float4*>(p.bias + co);
@@ -828,7 +832,7 @@ __global__ __launch_bounds__(512) void conv3x3_tall_kernel(sp_conv_params p, int
     // in front of every fragment's stores - the epilogue of a bias-only layer then has no load in its dependency chain
     // (per-item overhead was ~5 us of a 20 us item).  Average / max pooling commute with the bias; the x1/4 of the pooled
     // input gradient (in_up2) would scale it, so those launches (which carry no bias anyway) keep the epilogue form.
-    const bool bias_in_acc = p.bias != nullptr && !up;
+    const bool bias_in_acc = p.bias != nullptr && !up && p.img_scale == nullptr;   // (a scaled accumulator takes its bias in the epilogue)
     f32x4_t acc[4][NFR];
     auto init_acc = [&](int it) {
         f32x4_t b4[4];
@@ -1377,13 +1381,14 @@ __global__ __launch_bounds__(256) void conv3x3_cin8_kernel(sp_conv_params p) {
         }
         if (!co_ok) continue;
         const long pix0 = ((long)n * H + ty0 + row) * W + tx0 + i16;
+        const float sc = conv_img_scale(p, pix0);                            // (a tile row lies inside one image)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             float v[16];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r] + bias[i * 4 + r];
+                for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r] * sc + bias[i * 4 + r];
             conv_epilogue16<bf16>(p, v, pix0 + j * 16, co_b, false);
         }
     }
@@ -1612,6 +1617,7 @@ extern "C" int sp_conv2d_igemm(const sp_conv_params* pp, sp_stream_t stream) {
         // BASELINE.json config 5: e4m3 operands on the fp8 MFMA, the ping-pong 3x3 kernel only (conv_pp.hip)
         SP_CHECK_ARG(p.x_scale && p.w_scale && (!p.y8 || p.y8_inv_scale), "sp_conv2d_igemm: SP_F8 needs x_scale, w_scale (and y8_inv_scale with y8)");
         SP_CHECK_ARG(p.cin_p % 16 == 0 && p.cout % 16 == 0 && p.ldy % 16 == 0 && p.ldy >= p.cout, "sp_conv2d_igemm: SP_F8 needs cin_p, cout, ldy multiples of 16");
+        SP_CHECK_ARG(p.img_scale == nullptr, "sp_conv2d_igemm: SP_F8 does not take img_scale");
         SP_CHECK_ARG((p.act == SP_ACT_NONE || p.act == SP_ACT_RELU) && (p.pool2 == 0 || p.pool2 == 2) && !p.res1 && !p.res2 && !p.mask_src && !p.in_up2,
                      "sp_conv2d_igemm: SP_F8 supports act NONE / ReLU, pool2 0 / 2, no residuals, no mask_src, no in_up2");
         const int rc = sp_conv_pp_launch(p, 8, reinterpret_cast<hipStream_t>(stream));
@@ -1633,5 +1639,11 @@ extern "C" int sp_conv2d_igemm(const sp_conv_params* pp, sp_stream_t stream) {
                          p.mask_src == nullptr,
                      "sp_conv2d_igemm: pool2 needs a 3x3 layer with cout > 32, cout %% 16 == 0, h %% 8 == 0, w %% 32 == 0, ldy %% 8 == 0 and no mask_src");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (p.img_scale != nullptr) {
+        SP_CHECK_ARG(p.img_split >= 0 && p.img_split <= p.n, "sp_conv2d_igemm: img_split %d outside [0, n]", p.img_split);
+        sp_conv_params q = p;                              // first output pixel of the second group (pooled geometry with pool2)
+        q.split_pix_ = (int64_t)p.img_split * (p.pool2 ? (long)(p.h / 2) * (p.w_ / 2) : (long)p.h * p.w_);
+        return q.dtype == SP_F32 ? dispatch<float>(q, s) : dispatch<bf16>(q, s);
+    }
     return p.dtype == SP_F32 ? dispatch<float>(p, s) : dispatch<bf16>(p, s);
 }

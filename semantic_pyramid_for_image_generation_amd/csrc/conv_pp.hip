@@ -213,7 +213,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
         b_addr[ds] = lds_base + ((RW * wpx) * HP + frow + ds) * 64 + ((fslot ^ (((frow + ds) >> 1) & 3)) << 4);
     const unsigned bias_addr = lds_base + G::OFF_BIAS + (wco * 64 + (lane >> 4) * 16) * 4;
 
-    const bool bias_in_acc = !G::F8 && p.bias != nullptr && !up && cotiles * CO_T <= PP_BIAS_MAX;   // (SP_F8: the bias follows the scale)
+    const bool bias_in_acc = !G::F8 && p.bias != nullptr && !up && cotiles * CO_T <= PP_BIAS_MAX && p.img_scale == nullptr;   // (SP_F8 / two-group batches: the bias follows the scale)
     f32x4_t acc[4][NFR];
     // accumulators of an item start at its bias (LDS copy: no global load whose wait would drain the DMA queue).  Measured and not
     // kept: the first stage of an item taking the bias registers as the MFMA C operand instead of 64 moves (a fourth copy of the
@@ -378,6 +378,13 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
             }
             stamp(9);
             if constexpr (FAST) {
+                if (p.img_scale != nullptr) {                            // two-group batch: the item's image picks the scale (uniform)
+                    const float sc = p.img_scale[n >= p.img_split ? 1 : 0];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < NFR; ++j) acc[i][j] *= sc;
+                }
                 // ONE pass per epilogue operand over the whole 64-value tile of the lane (a handful of uniform branches per item, the
                 // eight loads of an operand in flight together) - the per-fragment form (each fragment: its own tests for bias / mask /
                 // residuals / activation, its own load -> wait) cost ~640 cycles per fragment, 5x its VALU work

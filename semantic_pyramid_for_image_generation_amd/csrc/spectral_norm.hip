@@ -448,6 +448,25 @@ extern "C" int sp_sn_forward(const sp_sn_layer* table_dev, int32_t n_layers, int
     return SP_OK;
 }
 
+// two forwards of one network inside one step (sp_conv_params.img_scale): per layer {1, sigma_a / sigma_b}
+__global__ void sn_pair_scales_kernel(const sp_sn_layer* __restrict__ table, int n_layers, const float* __restrict__ scratch_a,
+                                      const float* __restrict__ scratch_b, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_layers) return;
+    const long so = table[i].scratch_off + table[i].cols + 2L * table[i].rows;     // {sigma, 1 / sigma}
+    out[2 * i] = 1.f;
+    out[2 * i + 1] = scratch_a[so] * scratch_b[so + 1];
+}
+
+extern "C" int sp_sn_pair_scales(const sp_sn_layer* table_dev, int32_t n_layers, const float* scratch_a, const float* scratch_b,
+                                 float* out, sp_stream_t stream) {
+    SP_CHECK_ARG(table_dev && scratch_a && scratch_b && out && n_layers > 0, "sp_sn_pair_scales: bad args");
+    hipLaunchKernelGGL(sn_pair_scales_kernel, dim3(sp_div_up(n_layers, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), table_dev,
+                       n_layers, scratch_a, scratch_b, out);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
 extern "C" int sp_sn_backward(const float* dwsn, const float* w_orig, const float* layer_scratch, int32_t rows,
                               int32_t cols, int32_t cin, int32_t taps, int32_t cin_p, int32_t plain, float* dot_tmp,
                               int32_t dot_ready, float* grad, sp_stream_t stream) {
