@@ -14,6 +14,7 @@ results beyond floating-point summation order.  The kernel library itself reads 
     fuse_bn_upsample      SP_FUSE_BN_UPSAMPLE    0        CBN + LeakyReLU + bilinear x2 in one kernel (measured slower)
     pool2_bwd_fused       SP_POOL2_BWD_FUSED     1        pooled gradients read directly by dgrad / weight gradient (no full-resolution tensor)
     graph_after           SP_GRAPH_AFTER         3        ModelWrapper.train(): capture HIP graphs after this many eager iterations (0 = never)
+    d_pair                SP_D_PAIR              1        D(real) and D(fake) of the discriminator step as one two-group pass over 2B images (models.Discriminator.forward_pair)
     vgg_fp8               SP_VGG_FP8             0        BASELINE.json config 5: VGG-16's wide 3x3 layers on the fp8 MFMA; 1 = no-gradient pass, 2 = both passes (ops.set_vgg_fp8)
     lib_path              SEMPYR_LIB             (in-tree libsempyr.so)
 """
@@ -38,13 +39,15 @@ class Config:
     pool2_bwd_fused: bool = True
     graph_after: int = 3
     vgg_fp8: int = 0
+    d_pair: bool = True
 
     @classmethod
     def from_env(cls) -> "Config":
         return cls(direct_grads=_flag("SP_DIRECT_GRADS", True), fuse_lrelu_bwd=_flag("SP_FUSE_LRELU_BWD", True),
                    commute_1x1=_flag("SP_COMMUTE_1X1", True), fuse_pool2=_flag("SP_FUSE_POOL2", True),
                    fuse_act_pool=_flag("SP_FUSE_ACT_POOL", True), fuse_bn_upsample=_flag("SP_FUSE_BN_UPSAMPLE", False),
-                   pool2_bwd_fused=_flag("SP_POOL2_BWD_FUSED", True), graph_after=int(os.environ.get("SP_GRAPH_AFTER", "3")), vgg_fp8=int(os.environ.get("SP_VGG_FP8", "0")))
+                   pool2_bwd_fused=_flag("SP_POOL2_BWD_FUSED", True), graph_after=int(os.environ.get("SP_GRAPH_AFTER", "3")), vgg_fp8=int(os.environ.get("SP_VGG_FP8", "0")),
+                   d_pair=_flag("SP_D_PAIR", True))
 
 
 CFG = Config.from_env()

@@ -161,8 +161,11 @@ class ModelWrapper(object):
             if noise_d is None:
                 noise_d = torch.randn((images_real.shape[0], self.latent_dimensions), dtype=torch.float32, device=images_real.device)
             images_fake = G(input=noise_d, features=features_real, masks=masks, class_id=labels_f)
-        prediction_real = D(images_real, labels)
-        prediction_fake = D(images_fake, labels)
+        if CFG.d_pair and hasattr(D, "forward_pair") and D.training and images_fake.shape == images_real.shape:
+            prediction_real, prediction_fake = D.forward_pair(images_real, images_fake, labels)     # one trunk pass over 2B images
+        else:
+            prediction_real = D(images_real, labels)
+            prediction_fake = D(images_fake, labels)
         loss_d_real, loss_d_fake = self.discriminator_loss(prediction_real, prediction_fake)
         self._arm_reducer("d")
         (loss_d_real + loss_d_fake).backward()

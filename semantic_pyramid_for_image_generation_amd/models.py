@@ -432,6 +432,39 @@ class Discriminator(nn.Module):
             self._bank.end()
 
 
+    def forward_pair(self, input_a: torch.Tensor, input_b: torch.Tensor, class_id: torch.Tensor):
+        """``(self(input_a, class_id), self(input_b, class_id))`` - the discriminator step's D(real), D(fake)
+        (model_wrapper.py:153-155) - with the convolution trunk run ONCE over the 2B images: the two forwards share weight_orig
+        and differ only in the spectral-norm sigma (every forward advances the power iteration), which a per-group accumulator
+        scale in the convolution epilogue absorbs (ops.PairPass).  Twice the work items per launch (B = 20: 640 -> 1 280 items
+        of the 256-channel layers on 256 CUs - whole rounds instead of 2.5), half the launches.  The layers behind the trunk
+        (768 -> 128 linear, the (B, B, 128) head, which couples the samples of ONE forward) run per group.  Results equal two
+        separate calls up to fp32 rounding of the scale; no image gradients (the D step needs none)."""
+        dt = ops.compute_dtype()
+        ops.require_gpu(input_a)
+        if not (_COMMUTE_1X1 and _FUSE_ACT_POOL):
+            return self(input_a, class_id), self(input_b, class_id)
+        bank = self._bank
+        na = input_a.shape[0]
+        pair = bank.begin_pair(self.training, dt, input_a.device, na)
+        try:
+            L = self.layers
+            x = L[0](ops.ingest_image_pair(input_a, input_b, dt))
+            x = L[3](L[2](L[1](x)))
+            x = L[7](L[6](L[5](L[4](x))))
+            x = ops.adaptive_avgpool(x, 1, 1, ACT_LRELU).flatten(1)
+            xa, xb = ops.split_rows(x, na)
+            cls = _class_index(class_id)
+            out = []
+            for rows, call, handles in ((xa, pair.call_a, pair.handles_a), (xb, pair.call_b, pair.handles_b)):
+                bank.use_call(call, handles)
+                h = L[11](rows, ACT_LRELU)
+                out.append(ops.discriminator_head(h, self.embedding, self.classification, cls))
+            return out[0], out[1]
+        finally:
+            bank.end()
+
+
 # --------------------------------------------------------------------------------------------------
 # frozen VGG-16 feature pyramid
 # --------------------------------------------------------------------------------------------------

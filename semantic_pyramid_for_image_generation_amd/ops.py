@@ -272,6 +272,7 @@ class SpectralNormBank:
         self.group_count: List[int] = []
         self.win_touched, self.win_bias = set(), set()
         self.expected_passes = 1               # passes per window after which on_group_done fires (ModelWrapper: 2 for D, 1 for G)
+        self.pair: Optional["PairPass"] = None # set while the trunk of a two-group pass runs (begin_pair)
         self.on_group_done = None              # callable(start, stop): floats [start, stop) of `flat` are final (eager launches only)
 
     def set_groups(self, n_groups: int) -> None:
@@ -469,9 +470,27 @@ class SpectralNormBank:
             self.handles = hs
         return call
 
+    def begin_pair(self, training: bool, dtype, device, split: int) -> "PairPass":
+        """Two consecutive forwards of the bank (two power iterations: the reference's D(real) then D(fake)) for ONE two-group
+        pass.  Leaves forward a current (its packing serves the trunk) with `pair` set; use_call() switches between the two for
+        the layers that run per group."""
+        call_a = self.begin(training, dtype, device)
+        handles_a = self.handles
+        call_b = self.begin(training, dtype, device)
+        handles_b = self.handles
+        scales = torch.empty(2 * len(self.specs), dtype=torch.float32, device=device)
+        L.call("sp_sn_pair_scales", ptr(self.table_dev), len(self.specs), ptr(call_a.scratch), ptr(call_b.scratch), ptr(scales), stream())
+        pair = PairPass(call_a, call_b, handles_a, handles_b, scales, split)
+        self.current, self.handles, self.pair = call_a, handles_a, pair
+        return pair
+
+    def use_call(self, call: SNCall, handles, pair: Optional["PairPass"] = None) -> None:
+        self.current, self.handles, self.pair = call, handles, pair
+
     def end(self) -> None:
         self.current = None
         self.handles = None
+        self.pair = None
 
     def flat_ranges(self, bucket_floats: int):
         """Contiguous [start, stop) ranges covering the whole flat gradient buffer, the groups that finish first in a backward pass
@@ -548,13 +567,14 @@ def set_tuning(key: int, value: int) -> None:
 
 
 def conv_launch(x, w_ptr: int, bias, y, res1, res2, mask_src, slope: float, n, h, w, cin_p, cout, ldy, ksize, act,
-                dtype, pool2: bool = False, in_up2: bool = False, family: str = "fwd") -> None:
+                dtype, pool2: bool = False, in_up2: bool = False, family: str = "fwd", img_scale: int = 0, img_split: int = 0) -> None:
     if KERNEL_PROBE is not None:
         _probed(family, 2.0 * n * h * w * cin_p * cout * ksize * ksize, _is_halo128(n, h, w, cout, ksize),
-                lambda: _conv_launch(x, w_ptr, bias, y, res1, res2, mask_src, slope, n, h, w, cin_p, cout, ldy, ksize, act, dtype, pool2, in_up2),
+                lambda: _conv_launch(x, w_ptr, bias, y, res1, res2, mask_src, slope, n, h, w, cin_p, cout, ldy, ksize, act, dtype, pool2, in_up2,
+                                     img_scale, img_split),
                 (ksize, cin_p, cout, h, w, n))
         return
-    _conv_launch(x, w_ptr, bias, y, res1, res2, mask_src, slope, n, h, w, cin_p, cout, ldy, ksize, act, dtype, pool2, in_up2)
+    _conv_launch(x, w_ptr, bias, y, res1, res2, mask_src, slope, n, h, w, cin_p, cout, ldy, ksize, act, dtype, pool2, in_up2, img_scale, img_split)
 
 
 def conv_pool2_ok(h: int, w: int, cout: int, ksize: int) -> bool:
@@ -563,8 +583,11 @@ def conv_pool2_ok(h: int, w: int, cout: int, ksize: int) -> bool:
 
 
 def _conv_launch(x, w_ptr: int, bias, y, res1, res2, mask_src, slope: float, n, h, w, cin_p, cout, ldy, ksize, act,
-                 dtype, pool2: bool = False, in_up2: bool = False) -> None:
+                 dtype, pool2: bool = False, in_up2: bool = False, img_scale: int = 0, img_split: int = 0) -> None:
+    """img_scale: device ADDRESS of the two per-group accumulator scales of a two-group batch (include/sempyr.h), 0 = none."""
     p = L.SpConvParams()
+    if img_scale:
+        p.img_scale, p.img_split = img_scale, img_split
     p.x, p.w, p.bias, p.y = x.data_ptr(), w_ptr, (bias.data_ptr() if bias is not None else None), y.data_ptr()
     p.res1 = res1.data_ptr() if res1 is not None else None
     p.res2 = res2.data_ptr() if res2 is not None else None
@@ -622,14 +645,32 @@ def wgrad_workspace_floats(n, h, w, cin_p, cout, ksize, dtype) -> int:
     return v
 
 
+class PairPass:
+    """Two forwards of one network whose convolution trunk runs as ONE batch of two groups (the discriminator's D(real) and
+    D(fake) of a step, model_wrapper.py:153-155): images [0, split) belong to forward `a`, the rest to forward `b`, which ran one
+    more power iteration.  Every launch uses a's packing W / sigma_a with the per-group accumulator scales {1, sigma_a / sigma_b}
+    of its layer (sp_conv_params.img_scale); the weight gradient is taken per group - each into its own forward's arena, since the
+    spectral-norm backward of a group needs that group's (u, v, sigma)."""
+    __slots__ = ("call_a", "call_b", "handles_a", "handles_b", "scales", "split")
+
+    def __init__(self, call_a, call_b, handles_a, handles_b, scales, split):
+        self.call_a, self.call_b, self.handles_a, self.handles_b, self.scales, self.split = call_a, call_b, handles_a, handles_b, scales, split
+
+    def scale_ptr(self, slot: int) -> int:
+        return self.scales.data_ptr() + 8 * slot
+
+
 class _ConvFn(torch.autograd.Function):
-    """`handle` is the layer's output of _SNBankFn: it stands for weight_orig in the autograd graph."""
+    """`handle` is the layer's output of _SNBankFn: it stands for weight_orig in the autograd graph.  pair (a PairPass) with
+    handle_b = the same layer's handle of the second forward: a two-group batch."""
 
     @staticmethod
     def forward(ctx, x, handle, bias, res1, res2, pl: PackedLayer, ksize: int, act: int, cout: int, premasked: bool = False,
-                mask_input: bool = False, pool2: bool = False):
+                mask_input: bool = False, pool2: bool = False, handle_b=None, pair: Optional[PairPass] = None):
         require_gpu(x)
         ctx.premasked, ctx.mask_input, ctx.pool2 = premasked, mask_input, pool2
+        ctx.pair = pair
+        img_scale, img_split = (pair.scale_ptr(pl.slot), pair.split) if pair is not None else (0, 0)
         n, h, w, cin_p = dims(x)
         if cin_p != pl.cin_p:
             raise L.SempyrError("conv input has %d channels, packed weights expect %d" % (cin_p, pl.cin_p))
@@ -637,7 +678,8 @@ class _ConvFn(torch.autograd.Function):
             raise L.SempyrError("pool2 epilogue is not available for this layer (see conv_pool2_ok)")
         # pool2: y (and res1 / res2) live at the pooled resolution - avgpool2(conv) + bias + residuals, one launch
         y = nhwc_empty(n, cout, h // 2, w // 2, x.dtype, x.device) if pool2 else nhwc_empty(n, cout, h, w, x.dtype, x.device)
-        conv_launch(x, pl.fwd, bias, y, res1, res2, None, 0.0, n, h, w, cin_p, cout, cout, ksize, act, x.dtype, pool2)
+        conv_launch(x, pl.fwd, bias, y, res1, res2, None, 0.0, n, h, w, cin_p, cout, cout, ksize, act, x.dtype, pool2,
+                    img_scale=img_scale, img_split=img_split)
         ctx.pl, ctx.ksize, ctx.act, ctx.cout = pl, ksize, act, cout
         ctx.has_res = (res1 is not None, res2 is not None)
         ctx.save_for_backward(x, y if act != ACT_NONE else None)
@@ -659,7 +701,7 @@ class _ConvFn(torch.autograd.Function):
             dz = dy
         dres = dz if cout_p == cout else None
         need = ctx.needs_input_grad
-        ws_floats = wgrad_workspace_floats(n, h, w, cin_p, cout, ksize, dt) if need[1] else 0
+        ws_floats = wgrad_workspace_floats(ctx.pair.split if ctx.pair is not None else n, h, w, cin_p, cout, ksize, dt) if need[1] else 0
         # gradient of the fused average pooling: every pooled gradient spreads (x 1/4) over its 2x2 window.  The input- and
         # weight-gradient kernels read the pooled tensor through that expansion (in_up2 / sp_conv2d_wgrad_accum_pooled) where
         # they can; otherwise it is written out first.
@@ -676,9 +718,38 @@ class _ConvFn(torch.autograd.Function):
             # the dgrad packing has pl.cin rows; padded input channels (if any) receive an exact zero gradient
             dx = (nhwc_empty if pl.cin == cin_p else nhwc_zeros)(n, cin_p, h, w, dt, x.device)
             # mask_input: x is the LeakyReLU output of a `premasked` producer - multiply dx by lrelu'(x) in the epilogue
+            pair = ctx.pair
             conv_launch(dz, pl.dgrad, None, dx, None, None, x if ctx.mask_input else None, 0.2, n, h, w, pl.cout_p, pl.cin, cin_p,
-                        ksize, ACT_NONE, dt, in_up2=up2, family="dgrad")
-        if need[1]:
+                        ksize, ACT_NONE, dt, in_up2=up2, family="dgrad", img_scale=pair.scale_ptr(pl.slot) if pair is not None else 0,
+                        img_split=pair.split if pair is not None else 0)
+        dhb = None
+        if need[1] and ctx.pair is not None:
+            # two-group batch: one weight-gradient launch per group (contiguous image ranges of x and dz), each into the arena of
+            # ITS forward - the batched spectral-norm backward of a forward needs that forward's (u, v, sigma)
+            pair = ctx.pair
+            if not pair.call_a.bank.direct_grads:
+                raise L.SempyrError("a two-group pass needs the bank's direct gradients (ModelWrapper sets them up)")
+            for call, lo, hi in ((pair.call_a, 0, pair.split), (pair.call_b, pair.split, n)):
+                if hi <= lo:
+                    continue
+                plg = call.layers[pl.slot]
+                dwsn = call.dw_slot(plg)
+                dbg = call.db_slot(plg) if bias_needed(need, 2) else None
+                xg, dzg, ng = x.narrow(0, lo, hi - lo), dz.narrow(0, lo, hi - lo), hi - lo
+                wsg = wgrad_workspace_floats(ng, h, w, cin_p, cout, ksize, dt)
+                if up2 and wsg == 0:
+                    raise L.SempyrError("pooled weight gradient without a workspace plan for a group of %d images" % ng)
+                ws = torch.empty(wsg, dtype=torch.float32, device=x.device) if wsg else None
+
+                def launch_wgrad(xg=xg, dzg=dzg, dwsn=dwsn, dbg=dbg, ws=ws, wsg=wsg, ng=ng):
+                    L.call("sp_conv2d_wgrad_accum_pooled" if up2 else "sp_conv2d_wgrad_accum", ptr(xg), ptr(dzg), ptr(dwsn), ptr(dbg), ptr(ws),
+                           wsg, ng, h, w, cin_p, cout, cout_p, ksize, sp_dtype(dt), stream())
+                if KERNEL_PROBE is not None:
+                    _probed("wgrad", 2.0 * ng * h * w * cin_p * cout * ksize * ksize, False, launch_wgrad, (ksize, cin_p, cout, h, w, ng))
+                else:
+                    launch_wgrad()
+            dh = dhb = _zero1(x.device)
+        elif need[1]:
             # weight (+ bias) gradient accumulate into this layer's slots of the pass-wide arena; the spectral-norm
             # backward of all layers runs later, batched, in _SNBankFn.backward
             dwsn = pl.call.dw_slot(pl)
@@ -705,7 +776,7 @@ class _ConvFn(torch.autograd.Function):
             if dres is None:
                 raise L.SempyrError("residual gradient with padded channels is not supported")
         return (dx, dh, db, dres if ctx.has_res[0] and need[3] else None, dres if ctx.has_res[1] and need[4] else None,
-                None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, dhb, None)
 
 
 def bias_needed(need, idx) -> bool:
@@ -721,6 +792,12 @@ def sn_conv2d(x, module, ksize: int, act: int = ACT_NONE, res1=None, res2=None, 
     pl = packed_layer(module, module.training, x.dtype, x.device)
     if premasked and (act != ACT_LRELU or pad_channels(module.weight_orig.shape[0], x.dtype) != module.weight_orig.shape[0]):
         raise L.SempyrError("premasked needs a LeakyReLU epilogue and an unpadded channel count")
+    bank = getattr(module, "_sn_bank", None)
+    pair = bank.pair if bank is not None and bank.current is pl.call else None
+    if pair is not None:
+        hb = pair.handles_b[pl.slot] if pair.handles_b is not None else None
+        return _ConvFn.apply(x, pl.handle, module.bias, res1, res2, pl, ksize, act, module.weight_orig.shape[0], premasked, mask_input,
+                             pool2, hb, pair)
     return _ConvFn.apply(x, pl.handle, module.bias, res1, res2, pl, ksize, act, module.weight_orig.shape[0], premasked, mask_input,
                          pool2)
 
@@ -1035,6 +1112,42 @@ class _ScaleAddFn(torch.autograd.Function):
         return da, dy, dg
 
 
+class _SplitRowsFn(torch.autograd.Function):
+    """(B, K) rows -> rows [0, split) and [split, B) as two dense tensors (and back), through the library's copy pass - no
+    torch slicing / cat kernels in the autograd graph."""
+
+    @staticmethod
+    def forward(ctx, x, split):
+        require_gpu(x)
+        x = as_rows(x)
+        b, k = x.shape
+        esz = x.element_size()
+        ya = torch.empty((split, k), dtype=x.dtype, device=x.device)
+        yb = torch.empty((b - split, k), dtype=x.dtype, device=x.device)
+        L.call("sp_act_fwd", ptr(x), ptr(ya), split * k, ACT_NONE, sp_dtype(x.dtype), stream())
+        L.call("sp_act_fwd", ctypes.c_void_p(x.data_ptr() + split * k * esz), ptr(yb), (b - split) * k, ACT_NONE, sp_dtype(x.dtype), stream())
+        ctx.cfg = (b, k, split)
+        return ya, yb
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        b, k, split = ctx.cfg
+        ref = ga if ga is not None else gb
+        dx = torch.empty((b, k), dtype=ref.dtype, device=ref.device)
+        esz = dx.element_size()
+        for g, lo, rows in ((ga, 0, split), (gb, split, b - split)):
+            dst = ctypes.c_void_p(dx.data_ptr() + lo * k * esz)
+            if g is None:
+                dx.narrow(0, lo, rows).zero_()
+            else:
+                L.call("sp_act_fwd", ptr(as_rows(g, dx.dtype)), dst, rows * k, ACT_NONE, sp_dtype(dx.dtype), stream())
+        return dx, None
+
+
+def split_rows(x, split: int):
+    return _SplitRowsFn.apply(x, split)
+
+
 def scale_add(a, b, gamma):
     return _ScaleAddFn.apply(a, b, gamma)
 
@@ -1104,6 +1217,23 @@ class _IngestFn(torch.autograd.Function):
 
 def ingest_image(img, dtype, scale3=None, shift3=None):
     return _IngestFn.apply(img, dtype, scale3, shift3)
+
+
+def ingest_image_pair(img_a: torch.Tensor, img_b: torch.Tensor, dtype) -> torch.Tensor:
+    """Two image batches (any strides; fp32 or compute dtype) -> ONE padded NHWC batch [a | b] (no autograd: the discriminator
+    step needs no image gradients, model_wrapper.py:150-160)."""
+    with torch.no_grad():
+        require_gpu(img_a)
+        na, c, h, w = img_a.shape
+        nb = img_b.shape[0]
+        cp = pad_channels(c, dtype)
+        y = nhwc_empty(na + nb, cp, h, w, dtype, img_a.device)
+        esz = y.element_size()
+        for img, off in ((img_a.detach(), 0), (img_b.detach(), na)):
+            sn, scs, sh, sw = img.stride()
+            L.call("sp_ingest_image", ptr(img), sp_dtype(img.dtype), sn, scs, sh, sw, ctypes.c_void_p(y.data_ptr() + off * h * w * cp * esz),
+                   img.shape[0], c, h, w, cp, None, None, sp_dtype(dtype), stream())
+    return y
 
 
 def mask_concat(feat: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:

@@ -1,0 +1,113 @@
+"""The discriminator step's D(real) + D(fake) as ONE two-group pass (models.Discriminator.forward_pair; the reference runs two
+forwards, /root/reference/model_wrapper.py:153-155, each advancing the spectral-norm power iteration, models.py:128-135):
+predictions, every parameter gradient and the (u, v) buffers must equal two separate calls - to fp32 rounding in the parity
+mode, to storage rounding in bf16 - and the C ABI's per-group accumulator scale (sp_conv_params.img_scale) is held to a torch
+reference on every convolution route it touches."""
+import copy
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import golden_util as gu  # noqa: E402
+import semantic_pyramid_for_image_generation_amd as sp  # noqa: E402
+from semantic_pyramid_for_image_generation_amd import ops  # noqa: E402
+
+
+@pytest.fixture(autouse=True)
+def _dtype_reset():
+    yield
+    ops.set_compute_dtype(torch.float32)
+
+
+def _disc(cf, seed):
+    _, Dsd, _ = gu.synth_states({"cf": cf, "seed": seed})
+    D = sp.Discriminator(channel_factor=cf)
+    D.load_state_dict(Dsd)
+    D = D.cuda().train()
+    D._bank.direct_grads, D._bank.expected_passes = True, 2
+    return D
+
+
+@pytest.mark.parametrize("cf,batch,dtype,tol_pred,tol_grad", [(4, 4, torch.float32, 2e-5, 2e-4), (1, 6, torch.float32, 2e-5, 2e-4),
+                                                             (1, 20, torch.bfloat16, 3e-2, 6e-2)])
+def test_pair_pass_equals_two_forwards(cf, batch, dtype, tol_pred, tol_grad):
+    ops.set_compute_dtype(dtype)
+    g = torch.Generator().manual_seed(11)
+    real = (torch.rand(batch, 3, 256, 256, generator=g) * 2 - 1).cuda()
+    fake = (torch.rand(batch, 3, 256, 256, generator=g) * 2 - 1).cuda()
+    cls = torch.randint(0, 365, (batch,), generator=g)
+    labels = F.one_hot(cls, 365).long().cuda()
+    loss_fn = sp.LSGANDiscriminatorLoss()
+    outs = []
+    for mode in ("two", "pair"):
+        D = _disc(cf, 3)
+        if mode == "two":
+            pr, pf = D(real, labels), D(fake, labels)
+        else:
+            pr, pf = D.forward_pair(real, fake, labels)
+        lr, lf = loss_fn(pr, pf)
+        (lr + lf).backward()
+        D._bank.collect_extra()
+        torch.cuda.synchronize()
+        outs.append((pr.detach().float().clone(), pf.detach().float().clone(),
+                     {n: p.grad.detach().float().clone() for n, p in D.named_parameters() if p.grad is not None},
+                     {n: b.detach().clone() for n, b in D.named_buffers()}))
+    (pr0, pf0, g0, b0), (pr1, pf1, g1, b1) = outs
+    for a, b, tag in ((pr0, pr1, "real"), (pf0, pf1, "fake")):
+        err = float((a - b).abs().max() / a.abs().max())
+        assert err <= tol_pred, (tag, err)
+    assert set(g0) == set(g1) and len(g0) > 50
+    dens = sorted(float(g0[n].abs().max()) for n in g0)
+    floor = 1e-2 * dens[len(dens) // 2]           # a gradient that is rounding noise in exact arithmetic (the key convolution's bias
+    for n in g0:                                  # shifts every logit of a softmax row alike) is held to the typical scale instead
+        den = max(float(g0[n].abs().max()), floor)
+        err = float((g0[n] - g1[n]).abs().max()) / den
+        assert err <= tol_grad, (n, err)
+    for n in b0:                                  # u, v: two power iterations either way - identical arithmetic
+        assert torch.equal(b0[n], b1[n]), n
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [
+    # (cin, cout, ksize, h, w, pool2, up, act): one per convolution route the discriminator trunk takes
+    (8, 64, 3, 64, 64, 0, False, 1),        # 8-channel input (conv3x3_cin8 in bf16)
+    (64, 64, 3, 32, 64, 1, False, 0),       # Cout <= 64, pooled epilogue
+    (64, 128, 3, 32, 32, 0, False, 1),      # Cout > 64 (ping-pong FAST / tall)
+    (128, 128, 3, 32, 32, 1, False, 0),     # pooled epilogue, Cout > 64
+    (128, 64, 3, 32, 32, 0, True, 0),       # input gradient of a pooled layer (in_up2)
+    (256, 256, 3, 16, 16, 0, False, 1),     # 16-wide maps
+    (256, 512, 3, 8, 8, 0, False, 1),       # small-spatial split-K igemm + finalize
+    (512, 768, 3, 4, 4, 0, False, 0),
+    (64, 128, 1, 32, 32, 0, False, 0),      # 1x1 direct
+    (512, 768, 1, 2, 2, 0, False, 0),       # 1x1 split-K
+    (72, 40, 3, 24, 24, 0, False, 1),       # odd shapes: generic igemm
+])
+def test_img_scale_every_route(dt, case):
+    cin, cout, k, h, w, pool2, up, act = case
+    if dt == torch.float32:
+        cin = (cin + 3) // 4 * 4
+    torch.manual_seed(cin * 7 + cout)
+    n, split = 5, 2
+    x = ops.nhwc_empty(n, cin, h // 2 if up else h, w // 2 if up else w, dt, "cuda").normal_()
+    wt = (torch.randn(cout, k, k, cin, device="cuda") * 0.05).to(dt)
+    b = torch.randn(cout, device="cuda")
+    scales = torch.tensor([0.75, 1.5], device="cuda")
+    ho, wo = (h // 2, w // 2) if pool2 else (h, w)
+    res = ops.nhwc_empty(n, cout, ho, wo, dt, "cuda").normal_()
+    xin = 0.25 * F.interpolate(x.float(), scale_factor=2, mode="nearest") if up else x.float()
+    ref = F.conv2d(xin, wt.float().permute(0, 3, 1, 2), None, padding=k // 2)
+    if pool2:
+        ref = F.avg_pool2d(ref, 2)
+    per = torch.cat([scales[:1].expand(split), scales[1:].expand(n - split)])[:, None, None, None]
+    ref = ref * per + b[None, :, None, None] + res.float()
+    if act:
+        ref = F.leaky_relu(ref, 0.2)
+    for _ in range(2):
+        y = ops.nhwc_empty(n, cout, ho, wo, dt, "cuda").fill_(-7.0)
+        ops._conv_launch(x, wt.data_ptr(), b, y, res, None, None, 0.2, n, h, w, cin, cout, cout, k, act, dt, pool2, up,
+                         scales.data_ptr(), split)
+        err = float((y.float() - ref).abs().max() / ref.abs().max())
+        assert err <= (3e-4 if dt == torch.float32 else 1e-2), (case, err)
