@@ -35,7 +35,8 @@ sys.path.insert(0, ROOT)
 # Algorithmic FLOPs per image of the full step (2 x MACs of every conv / linear / bmm), necessary work only
 # (SURVEY.md section 8d): D-step 210.40 + G-step 199.34 GFLOP at channel_factor = 1.
 GFLOP_PER_IMAGE = {1: 409.74, 2: 197.75, 0.5: 1239.60}
-PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}      # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "f32": 157.3}      # dense MFMA peaks, MI355X_MICROARCH.md
+TORCH_DTYPE = {"bf16": torch.bfloat16, "fp16": torch.float16, "f32": torch.float32}
 DOMINANT_KERNEL = "conv3x3_pp_kernel<bf16,2> (sp_conv2d_igemm, 3x3, Cout>64, 128 co x 8x32 px tiles, ping-pong schedule)"
 DOMINANT_KERNEL_SYMBOL = r"conv3x3_pp_kernel<bf16, 2, [^>]*, 2>\("      # regex: both epilogue forms on 32-wide tiles (not the 16-wide form)
 TRAFFIC_FILES = ("round4_hbm_traffic_per_kernel.json", "round3_hbm_traffic_per_kernel.json", "round2_hbm_traffic_per_kernel.json")
@@ -49,7 +50,11 @@ def parse():
     p.add_argument("--warmup", type=int, default=10)
     p.add_argument("--batch", type=int, default=20, help="batch per GPU")
     p.add_argument("--channel-factor", type=float, default=1)
-    p.add_argument("--dtype", choices=("bf16", "f32"), default="bf16")
+    p.add_argument("--dtype", choices=("bf16", "f32", "fp16"), default="bf16",
+                   help="storage type of activations / packed weights: bf16 (headline, BASELINE config 2), f32 (parity mode), fp16 "
+                        "(BASELINE config 5's activations; static loss scale)")
+    p.add_argument("--fp8", action="store_true", help="BASELINE config 5: e4m3 operands on the fp8 MFMA for the VGG-16 pyramid's wide 3x3 "
+                                                      "layers in the no-gradient pass (ops.set_vgg_fp8(1)); with --dtype fp16 this is the config-5 line")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-probe", action="store_true")
     p.add_argument("--no-sub-records", action="store_true", help="skip the fp32 parity-mode and batch-32 sub-records")
@@ -355,7 +360,7 @@ class Job:
         import semantic_pyramid_for_image_generation_amd as sp
         from semantic_pyramid_for_image_generation_amd import distributed, ops, params, synthetic
         self.batch, self.world = batch, world
-        dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
+        dtype = TORCH_DTYPE[dtype_name]
         ops.set_compute_dtype(dtype)
         torch.manual_seed(0)                                     # identical G/D init on every rank (default init, seed 0)
         G = sp.Generator(channels_factor=cf).to(dev)
@@ -475,7 +480,7 @@ def sub_record(cf, batch, dtype_name, dev, steps, warmup, use_graphs):
     return rec
 
 
-def bf16_parity_record(dev, tag="step_cf1_b2_seed0"):
+def bf16_parity_record(dev, tag="step_cf1_b2_seed0", dtype_name="bf16"):
     """The benchmarked (bf16) mode against the committed reference goldens of the two-iteration loop (tests/golden/<tag>: loss
     scalars and 4096 generator-pixel samples recorded from the unmodified reference, tests/golden/make_golden.py): the MEASURED
     errors of this very build, so that the throughput figure and "matches the reference" are statements about one program.
@@ -490,7 +495,7 @@ def bf16_parity_record(dev, tag="step_cf1_b2_seed0"):
     import make_golden                                           # committed generator of the golden batches (data only)
     meta = _json.load(open(os.path.join(gold, tag + ".json")))
     arr = dict(np.load(os.path.join(gold, tag + ".npz")))
-    ops.set_compute_dtype(torch.bfloat16)
+    ops.set_compute_dtype(TORCH_DTYPE[dtype_name])
     G, D, V = sp.Generator(channels_factor=meta["cf"]), sp.Discriminator(channel_factor=meta["cf"]), sp.VGG16()
     for net, seed in ((G, meta["seed"]), (D, meta["seed"] + 1), (V, meta["seed"] + 2)):
         net.load_state_dict(params.synth_state_dict(net.state_dict(), seed))
@@ -516,7 +521,7 @@ def bf16_parity_record(dev, tag="step_cf1_b2_seed0"):
     return {"against": "reference goldens tests/golden/%s (cf=%s, batch %d, 2 iterations of the reference's own loop)" % (tag, meta["cf"], meta["batch_size"]),
             "worst_loss_rel_err": round(max(rec["loss_rel"]), 6), "worst_pixel_abs_err": round(max(rec["pixel_max"]), 5),
             "pixel_rms_err": round(max(rec["pixel_rms"]), 5), "fp32_mode_bound": 1e-3,
-            "note": "bf16 storage + bf16 MFMA + fp32 accumulate vs the fp32 reference; the fp32 parity mode meets 1e-3 (parity_mode record)"}
+            "note": "%s storage + %s MFMA + fp32 accumulate vs the fp32 reference; the fp32 parity mode meets 1e-3 (parity_mode record)" % (dtype_name, dtype_name)}
 
 
 def flush_c_stdio():

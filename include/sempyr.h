@@ -14,7 +14,7 @@
  *     (thread-local).  Nothing throws.
  *   - Activations are NHWC ("channels-last"): element (n,h,w,c) at ((n*H+h)*W+w)*ld + c, where ld is
  *     the channel pitch in elements.  `dtype` selects the HBM storage type of activations and packed
- *     weights (SP_F32 / SP_BF16); accumulation is always fp32.  Master weights, biases, statistics,
+ *     weights (SP_F32 / SP_BF16 / SP_F16); accumulation is always fp32.  Master weights, biases, statistics,
  *     gradients of parameters and loss scalars are always fp32.
  *   - Packed conv weights: [Cout][kh*kw][cin_p] (K-contiguous per output channel), cin_p = Cin rounded
  *     up to a 16-byte multiple.  The same kernel computes the input gradient from the "dgrad" packing
@@ -33,7 +33,10 @@ extern "C" {
 typedef void* sp_stream_t;
 
 enum sp_status { SP_OK = 0, SP_ERR_INVALID = -1, SP_ERR_LAUNCH = -2, SP_ERR_UNSUPPORTED = -3 };
-enum sp_dtype { SP_F32 = 0, SP_BF16 = 1, SP_F8 = 2 /* OCP e4m3 operands, see sp_conv_params: x_scale .. y8_amax */ };
+enum sp_dtype { SP_F32 = 0, SP_BF16 = 1, SP_F8 = 2 /* OCP e4m3 operands, see sp_conv_params: x_scale .. y8_amax; 16-bit outputs bf16 */,
+                SP_F16 = 3 /* IEEE half-precision storage, v_mfma_f32_16x16x32_f16, fp32 accumulate: accepted wherever SP_BF16 is (same
+                            * layouts, same kernels compiled for the other 16-bit type) - BASELINE.json config 5's "fp16 activations" */,
+                SP_F8_F16 = 4 /* sp_conv2d_igemm only: SP_F8 operands with fp16 (not bf16) 16-bit outputs */ };
 enum sp_act { SP_ACT_NONE = 0, SP_ACT_LRELU = 1, SP_ACT_RELU = 2, SP_ACT_TANH = 3 };
 
 int sp_version(void);
@@ -429,6 +432,11 @@ typedef struct sp_adam_chunk {
 /* hyper-parameters are doubles: torch derives (1 - beta) from the Python float and only then rounds to fp32 */
 int sp_adam_multi(const sp_adam_chunk* chunks_dev, int32_t n_chunks, double beta1, double beta2, double eps,
                   double weight_decay, sp_stream_t stream);
+
+/* x[i] *= factor for an fp32 buffer (16-byte aligned), in place: takes the static loss scale of the SP_F16 storage mode off a
+ * network's flat gradient buffer before the optimizer step (the activation gradients of this network - means over 5e4 ... 5e6
+ * elements - would be subnormal in fp16 without it; the reference trains in fp32, model_wrapper.py:160,188). */
+int sp_scale_f32(float* x, int64_t numel, float factor, sp_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "sempyr.h")
 LIB_PATH = os.environ.get("SEMPYR_LIB") or os.path.join(_HERE, "libsempyr.so")     # SEMPYR_LIB: A/B runs of two builds
 
-SP_F32, SP_BF16, SP_F8 = 0, 1, 2
+SP_F32, SP_BF16, SP_F8, SP_F16, SP_F8_F16 = 0, 1, 2, 3, 4
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 
 # sp_set_tuning keys (include/sempyr.h).  The library reads no environment variables itself; an environment variable of

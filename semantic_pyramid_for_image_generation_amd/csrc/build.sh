@@ -1,19 +1,40 @@
 #!/bin/bash
 # Builds libsempyr.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
+#
+# Every kernel source is compiled TWICE (common.h: the 16-bit flavour is a compile-time choice of the translation unit):
+#   build/<f>.o      bf16 + fp32 kernels, entry points renamed sp_x__b16 (build/rename_b16.h)
+#   build/<f>.h16.o  -DSP_H16_FP16: the same 16-bit code paths on fp16 storage / v_mfma_f32_16x16x32_f16, entry points sp_x__h16
+# and build/dispatch_h16.cpp (generated from include/sempyr.h by tools/gen_h16.py) holds the public entry points.
+# An object is rebuilt when its source, a header or this script is newer; objects that are not part of the library are removed
+# (a stale object of a parked experiment next to product objects proves nothing about the sources - round-3 VERDICT).
 set -e
 cd "$(dirname "$0")"
 OUT=../libsempyr.so
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result -Wno-pass-failed"
+SRCS="conv_igemm conv_pp fp8 conv_wgrad conv_wgrad_rows conv_wgrad_1x1 spectral_norm linear eltwise norm resample attention losses optim"
 mkdir -p build
+python3 ../../tools/gen_h16.py build > /dev/null
+keep=" api.o dispatch_h16.o"
+for f in $SRCS; do keep="$keep $f.o $f.h16.o"; done
+for o in build/*.o; do
+  [ -e "$o" ] || continue
+  case "$keep " in *" $(basename $o) "*) ;; *) rm -f "$o" ;; esac
+done
+stale() {  # stale <object> <source>
+  [ ! -f "$1" ] || [ "$2" -nt "$1" ] || [ common.h -nt "$1" ] || [ conv_common.h -nt "$1" ] || [ ../../include/sempyr.h -nt "$1" ] \
+    || [ build.sh -nt "$1" ] || [ ../../tools/gen_h16.py -nt "$1" ]
+}
+JOBS=${SP_BUILD_JOBS:-8}
+running=0
 pids=()
-for f in conv_igemm conv_pp fp8 conv_wgrad conv_wgrad_rows conv_wgrad_1x1 spectral_norm linear eltwise norm resample attention losses optim; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ conv_common.h -nt build/$f.o ] || [ ../../include/sempyr.h -nt build/$f.o ]; then
-    hipcc $FLAGS -c $f.hip -o build/$f.o &
-    pids+=($!)
-  fi
+launch() { "$@" & pids+=($!); running=$((running + 1)); if [ $running -ge $JOBS ]; then wait -n; running=$((running - 1)); fi; }
+for f in $SRCS; do
+  if stale build/$f.o $f.hip; then launch hipcc $FLAGS -include build/rename_b16.h -c $f.hip -o build/$f.o; fi
+  if stale build/$f.h16.o $f.hip; then launch hipcc $FLAGS -DSP_H16_FP16 -include build/rename_h16.h -c $f.hip -o build/$f.h16.o; fi
 done
 for p in "${pids[@]}"; do wait $p; done
 hipcc $FLAGS -c api.cpp -o build/api.o
-OBJS=""; for f in conv_igemm conv_pp fp8 conv_wgrad conv_wgrad_rows conv_wgrad_1x1 spectral_norm linear eltwise norm resample attention losses optim api; do OBJS="$OBJS build/$f.o"; done
+hipcc $FLAGS -c build/dispatch_h16.cpp -o build/dispatch_h16.o
+OBJS="build/api.o build/dispatch_h16.o"; for f in $SRCS; do OBJS="$OBJS build/$f.o build/$f.h16.o"; done
 hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $OUT
 echo "built $(realpath $OUT)"

@@ -4,22 +4,48 @@
 #include <stdint.h>
 #include "../../include/sempyr.h"
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef float sp_f32x2_t __attribute__((ext_vector_type(2)));
 
 // Storage element types.  Arithmetic is always fp32; T only selects the HBM format.
+//
+// THE 16-BIT FLAVOUR IS A COMPILE-TIME CHOICE OF THE TRANSLATION UNIT.  Every kernel source is compiled twice (build.sh): as is -
+// `bf16` = bfloat16, the MFMA is v_mfma_f32_16x16x32_bf16 (SP_BF16) - and with -DSP_H16_FP16, where the SAME 16-bit code paths
+// store IEEE half precision and multiply on v_mfma_f32_16x16x32_f16 (SP_F16: BASELINE.json config 5's "fp16 activations"; 10
+// mantissa bits instead of 7).  Layouts, LDS images, transposed reads and schedules are 16-bit agnostic; what differs is exactly
+// what is defined in this block: the two conversions, the MFMA, the constant 1.0.  The second compilation's entry points carry the
+// suffix __h16 (build/rename_h16.h) and are reached through the dispatcher generated from include/sempyr.h (tools/gen_h16.py).
 struct bf16 { uint16_t v; };
-
+#ifdef SP_H16_FP16
+typedef __attribute__((ext_vector_type(8))) _Float16 bf16x8_t;
+typedef _Float16 sp_h16x2_t __attribute__((ext_vector_type(2)));
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define SP_H16_ONE_PAIR 0x3C003C00u                       // two 1.0 values
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t h) { return (float)__builtin_bit_cast(_Float16, (uint16_t)h); }
+// fp32 -> fp16, round-to-nearest-even (v_cvt_pk_f16_f32 on gfx950); values beyond 65504 become inf - the host keeps the
+// activation gradients in range with a static loss scale (ops.py)
+__device__ __forceinline__ uint32_t f32x2_to_bf16x2(float lo, float hi) {
+    const sp_f32x2_t f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, sp_h16x2_t));
+}
+// the two halves of a packed pair as fp32
+__device__ __forceinline__ float h16_lo_to_f32(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu)); }
+__device__ __forceinline__ float h16_hi_to_f32(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); }
+#else
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __bf16 sp_bf16x2_t __attribute__((ext_vector_type(2)));
+#define SP_H16_ONE_PAIR 0x3F803F80u
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
 // fp32 -> bf16, round-to-nearest-even, NaN kept quiet: gfx950 has the packed conversion in hardware (v_cvt_pk_bf16_f32, one
 // instruction per two values; the integer sequence it replaces cost 7 VALU per value - measurable in every bf16 epilogue)
-typedef __bf16 sp_bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float sp_f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t f32x2_to_bf16x2(float lo, float hi) {
     const sp_f32x2_t f = {lo, hi};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, sp_bf16x2_t));
 }
+__device__ __forceinline__ float h16_lo_to_f32(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float h16_hi_to_f32(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+#endif
 __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) { return f32x2_to_bf16x2(f, 0.f) & 0xffffu; }
 
 template <typename T> struct Elem;

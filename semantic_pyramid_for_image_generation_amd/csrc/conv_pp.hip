@@ -414,8 +414,8 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
                             for (int k = 0; k < 8; ++k) {
                                 const uint4& u = t[jj][k >> 2];
                                 const uint32_t w = (k & 3) == 0 ? u.x : (k & 3) == 1 ? u.y : (k & 3) == 2 ? u.z : u.w;
-                                acc[k >> 1][jj][2 * (k & 1)] = apply(acc[k >> 1][jj][2 * (k & 1)], __uint_as_float(w << 16));
-                                acc[k >> 1][jj][2 * (k & 1) + 1] = apply(acc[k >> 1][jj][2 * (k & 1) + 1], __uint_as_float(w & 0xffff0000u));
+                                acc[k >> 1][jj][2 * (k & 1)] = apply(acc[k >> 1][jj][2 * (k & 1)], h16_lo_to_f32(w));
+                                acc[k >> 1][jj][2 * (k & 1) + 1] = apply(acc[k >> 1][jj][2 * (k & 1) + 1], h16_hi_to_f32(w));
                             }
                     };
                     if (p.mask_src != nullptr) {

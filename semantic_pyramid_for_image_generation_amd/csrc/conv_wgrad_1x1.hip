@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_stream_kernel(W1Args a) {
         fb[i] = lds_base + (unsigned)(W1_TILE + row1 * 128 + (((wb * 2 + i) ^ key) * 32) + (i16 & 3) * 8);
     }
     const bool do_bias = a.dbias != nullptr && ci0 == 0 && wb == 0;       // wave-uniform
-    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(SP_H16_ONE_PAIR, SP_H16_ONE_PAIR, SP_H16_ONE_PAIR, SP_H16_ONE_PAIR));
     f32x4_t acc[2][2], accb[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_cin8_stream_kernel(W1Args a, 
         fb[j] = lds_base + (unsigned)(W1_TILE + row1 * C8_BPITCH + f * 32 + (i16 & 3) * 8);
     }
     const bool do_bias = a.dbias != nullptr && wb == 0;
-    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(SP_H16_ONE_PAIR, SP_H16_ONE_PAIR, SP_H16_ONE_PAIR, SP_H16_ONE_PAIR));
     f32x4_t acc[2][3], accb[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {

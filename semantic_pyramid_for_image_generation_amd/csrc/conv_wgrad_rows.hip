@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_rows_kernel(WrArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) accb[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const bool do_bias = a.dbias != nullptr && ci0 == 0 && (thin || wave == 0);    // thin: every wave sums the rows it owns
-    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(SP_H16_ONE_PAIR, SP_H16_ONE_PAIR, SP_H16_ONE_PAIR, SP_H16_ONE_PAIR));
 
     int n_last = 0;
     issue_stage();
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_pp_kernel(WrArgs a, int rows_p
 #pragma unroll
     for (int i = 0; i < 4; ++i) accb[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const bool do_bias = a.dbias != nullptr && ci0 == 0 && wq == 0;
-    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(SP_H16_ONE_PAIR, SP_H16_ONE_PAIR, SP_H16_ONE_PAIR, SP_H16_ONE_PAIR));
 
     // ---- prologue: steps 0 .. D-1 (each half requests the steps of its parity), everything landed before the first read.  Only
     // the REQUEST cursor exists; whether the step being computed is a row step comes out of a two-entry history of its phases
@@ -791,7 +791,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_pp3_kernel(WrArgs a, int rows_
 #pragma unroll
     for (int i = 0; i < 4; ++i) accb[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const bool do_bias = a.dbias != nullptr && ci0 == 0 && wq == 0;
-    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(SP_H16_ONE_PAIR, SP_H16_ONE_PAIR, SP_H16_ONE_PAIR, SP_H16_ONE_PAIR));
 
     // ---- cursors: rq = the step being requested (D steps ahead), (cy, cphase) = row / phase of the step being computed
     Cursor rq;

@@ -399,7 +399,7 @@ __device__ __forceinline__ unsigned long long sp_draw(unsigned long long seed, u
 
 struct sp_mask_ptrs { float* m[7]; };          // list order of the reference: 128^2, 64^2, 32^2, 16^2, 8^2, 4096, 365
 
-__global__ __launch_bounds__(256) void training_masks_kernel(sp_mask_ptrs out, unsigned long long seed, unsigned thresh24) {
+static __global__ __launch_bounds__(256) void training_masks_kernel(sp_mask_ptrs out, unsigned long long seed, unsigned thresh24) {
     const unsigned b = blockIdx.x;
     const int stage_tab[9] = {0, 1, 2, 3, 4, 5, 6, 0, 1};
     const int side_of[7] = {1, 1, 8, 16, 32, 64, 128};         // side of level idx (counted from the deep end); 0 / 1 are vectors

@@ -45,7 +45,28 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const sp_adam_chunk* __
     }
 }
 
+__global__ __launch_bounds__(256) void scale_f32_kernel(float* __restrict__ x, long n4, long n, float f) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 v = reinterpret_cast<float4*>(x)[i];
+        v.x *= f; v.y *= f; v.z *= f; v.w *= f;
+        reinterpret_cast<float4*>(x)[i] = v;
+    }
+    for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) x[i] *= f;
+}
+
 }  // namespace
+
+extern "C" int sp_scale_f32(float* x, int64_t numel, float factor, sp_stream_t stream) {
+    SP_CHECK_ARG(x && numel > 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "sp_scale_f32: bad args (16-byte aligned pointer, numel > 0)");
+    long blocks = (numel / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(scale_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, (long)(numel / 4),
+                       (long)numel, factor);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
 
 extern "C" int sp_adam_multi(const sp_adam_chunk* chunks_dev, int32_t n_chunks, double beta1, double beta2, double eps,
                              double weight_decay, sp_stream_t stream) {

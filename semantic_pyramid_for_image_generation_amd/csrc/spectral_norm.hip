@@ -449,7 +449,7 @@ extern "C" int sp_sn_forward(const sp_sn_layer* table_dev, int32_t n_layers, int
 }
 
 // two forwards of one network inside one step (sp_conv_params.img_scale): per layer {1, sigma_a / sigma_b}
-__global__ void sn_pair_scales_kernel(const sp_sn_layer* __restrict__ table, int n_layers, const float* __restrict__ scratch_a,
+static __global__ void sn_pair_scales_kernel(const sp_sn_layer* __restrict__ table, int n_layers, const float* __restrict__ scratch_a,
                                       const float* __restrict__ scratch_b, float* __restrict__ out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_layers) return;

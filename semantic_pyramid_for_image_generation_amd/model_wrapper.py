@@ -107,7 +107,8 @@ class ModelWrapper(object):
             return
         bank.on_group_done = None
         self._fired = set()
-        if self.gradient_reducer is not None and not self._capturing and self.gradient_reducer.active():
+        # (fp16 mode: the loss scale comes off the whole flat buffer after the backward pass - ranges go to the wire only then)
+        if self.gradient_reducer is not None and not self._capturing and self.gradient_reducer.active() and ops.loss_scale() == 1.0:
             red = self.gradient_reducer
 
             def done(start, stop, bank=bank):
@@ -123,6 +124,10 @@ class ModelWrapper(object):
         if bank is not None:
             bank.on_group_done = None
             bank.collect_extra()
+            if bank.flat is not None:
+                ops.unscale_(bank.flat)                 # fp16 mode: the static loss scale comes off the (fp32) parameter gradients
+        elif ops.loss_scale() != 1.0:
+            raise ops.L.SempyrError("the fp16 storage mode needs the flat gradient buffers (config.CFG.direct_grads) for its loss scale")
 
     def _start_reduce(self, key: str, params, eager: bool) -> None:
         """Enqueues (side stream) whatever of the network's gradients has not been handed over by the group hooks."""
@@ -168,7 +173,7 @@ class ModelWrapper(object):
             prediction_fake = D(images_fake, labels)
         loss_d_real, loss_d_fake = self.discriminator_loss(prediction_real, prediction_fake)
         self._arm_reducer("d")
-        (loss_d_real + loss_d_fake).backward()
+        (loss_d_real + loss_d_fake).backward(gradient=ops.loss_scale_seed(images_real.device))
         self._finish_backward("d")
         return features_real, loss_d_real, loss_d_fake
 
@@ -194,7 +199,8 @@ class ModelWrapper(object):
             features_fake = V(images_fake)
             loss_rec = w_rec * self.semantic_reconstruction_loss(features_real, features_fake, masks)
             self._arm_reducer("g")
-            (loss_g + loss_rec + loss_div).backward()
+            seed = ops.loss_scale_seed(images_fake.device)      # the total is shape (1,) like the reference's (lossfunction.py:42)
+            (loss_g + loss_rec + loss_div).backward(gradient=seed.reshape(1) if seed is not None else None)
             self._finish_backward("g")
         finally:
             for p in self._d_params:

@@ -738,7 +738,7 @@ class VGG16(nn.Module):
                 ops.L.call("sp_pack_weight", ops.ptr(w), o, k, k, 1, kp, np_, chw[0], chw[1], ops.ptr(fwd), ops.ptr(dg), sd, ops.stream())
                 packs["fc"].append({"fwd": fwd, "dgrad": dg, "kp": kp, "np": np_, "n": o,
                                     "bias": m.bias.detach().to(device=device, dtype=torch.float32).contiguous()})
-            if ops.vgg_fp8() > 0 and dtype == torch.bfloat16:
+            if ops.vgg_fp8() > 0 and ops.is_16bit(dtype):
                 # BASELINE.json config 5: e4m3 filters (one scale per output channel) for every 3x3 layer the fp8 kernel can take
                 # (Cout > 64, Cin a multiple of 16); activation scales start uncalibrated (the first forward runs in bf16 and records them)
                 f8w, ci = {}, 0

@@ -3,7 +3,8 @@
 PyTorch is plumbing here (device memory, streams, the autograd graph); every arithmetic pass over an
 activation or weight goes through the C ABI of include/sempyr.h.  Activations are torch tensors of
 LOGICAL shape (N, C, H, W) whose memory is dense NHWC ("channels_last"), in the compute dtype
-(float32 for the parity mode, bfloat16 for the throughput mode); 2-D activations are (B, K) row-major.
+(float32 for the parity mode, bfloat16 for the throughput mode, float16 for BASELINE.json config 5); 2-D activations are (B, K)
+row-major.
 """
 from __future__ import annotations
 
@@ -18,14 +19,53 @@ from .config import CFG
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = L.ACT_NONE, L.ACT_LRELU, L.ACT_RELU, L.ACT_TANH
 
-_STATE = {"dtype": torch.float32, "vgg_fp8": int(CFG.vgg_fp8)}
+_STATE = {"dtype": torch.float32, "vgg_fp8": int(CFG.vgg_fp8), "loss_scale": float(CFG.f16_loss_scale)}
 
 
 def set_compute_dtype(dtype: torch.dtype) -> None:
-    """float32: exact-fp32 MFMA path used for parity; bfloat16: bf16 MFMA, fp32 accumulate."""
-    if dtype not in (torch.float32, torch.bfloat16):
-        raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
+    """float32: exact-fp32 MFMA path used for parity; bfloat16: bf16 MFMA, fp32 accumulate; float16 (BASELINE.json config 5,
+    "fp16 activations"): the same kernels compiled for IEEE half storage / v_mfma_f32_16x16x32_f16 (SP_F16) - 10 mantissa bits
+    instead of 7, but 5 exponent bits: ModelWrapper multiplies the loss gradient by loss_scale() so that the activation
+    gradients (1e-5 ... 1e-9 in this network: means over 51 200 / 5.2 M elements) stay above fp16's 6e-5 normal range, and
+    divides the parameter gradients by it again (they are fp32 in every mode)."""
+    if dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        raise ValueError("compute dtype must be torch.float32, torch.bfloat16 or torch.float16")
     _STATE["dtype"] = dtype
+
+
+def is_16bit(dtype: torch.dtype) -> bool:
+    return dtype in (torch.bfloat16, torch.float16)
+
+
+def loss_scale() -> float:
+    """Static factor on the loss gradient in the fp16 mode (config.CFG.f16_loss_scale, default 2^16); 1.0 otherwise."""
+    return float(_STATE["loss_scale"]) if _STATE["dtype"] == torch.float16 else 1.0
+
+
+def set_loss_scale(value: float) -> None:
+    _STATE["loss_scale"] = float(value)
+
+
+_SCALE_SEED = {}
+
+
+def loss_scale_seed(device) -> Optional[torch.Tensor]:
+    """The `gradient=` argument of .backward() that carries the loss scale (a cached 0-dim tensor: no kernel), or None."""
+    s = loss_scale()
+    if s == 1.0:
+        return None
+    key = (str(device), s)
+    t = _SCALE_SEED.get(key)
+    if t is None:
+        t = _SCALE_SEED[key] = torch.full((), s, dtype=torch.float32, device=device)
+    return t
+
+
+def unscale_(flat: torch.Tensor) -> None:
+    """flat *= 1 / loss_scale(), in place, one launch of the library (no-op outside the fp16 mode)."""
+    s = loss_scale()
+    if s != 1.0:
+        L.call("sp_scale_f32", ptr(flat), flat.numel(), 1.0 / s, stream())
 
 
 def compute_dtype() -> torch.dtype:
@@ -45,7 +85,7 @@ def set_vgg_fp8(mode) -> None:
 
 
 def vgg_fp8() -> int:
-    return int(_STATE.get("vgg_fp8", 0)) if _STATE["dtype"] == torch.bfloat16 else 0
+    return int(_STATE.get("vgg_fp8", 0)) if is_16bit(_STATE["dtype"]) else 0
 
 
 def sp_dtype(dtype: torch.dtype) -> int:
@@ -53,6 +93,8 @@ def sp_dtype(dtype: torch.dtype) -> int:
         return L.SP_F32
     if dtype == torch.bfloat16:
         return L.SP_BF16
+    if dtype == torch.float16:
+        return L.SP_F16
     raise TypeError("unsupported activation dtype %s" % dtype)
 
 
@@ -705,7 +747,7 @@ class _ConvFn(torch.autograd.Function):
         # gradient of the fused average pooling: every pooled gradient spreads (x 1/4) over its 2x2 window.  The input- and
         # weight-gradient kernels read the pooled tensor through that expansion (in_up2 / sp_conv2d_wgrad_accum_pooled) where
         # they can; otherwise it is written out first.
-        up2 = ctx.pool2 and _POOL2_BWD_FUSED and dt == torch.bfloat16 and (not need[0] or conv_pool2_ok(h, w, pl.cin, ksize)) \
+        up2 = ctx.pool2 and _POOL2_BWD_FUSED and is_16bit(dt) and (not need[0] or conv_pool2_ok(h, w, pl.cin, ksize)) \
             and (not need[1] or ws_floats > 0)
         if ctx.pool2 and not up2:
             dz_full = nhwc_empty(n, cout_p, h, w, dt, x.device)
@@ -805,7 +847,7 @@ def sn_conv2d(x, module, ksize: int, act: int = ACT_NONE, res1=None, res2=None, 
 def linear_launch(x, w_ptr: int, kp: int, bias, res, y, b: int, k: int, n: int, act: int) -> None:
     """y[b][n] = act(x W^T + bias + res); large bf16 matrices go through the MFMA split-K path (fp32 scratch)."""
     scratch = None
-    if x.dtype == torch.bfloat16 and b <= 32:
+    if is_16bit(x.dtype) and b <= 32:
         key = (b, k, n)
         floats = _LIN_WS_CACHE.get(key)
         if floats is None:
@@ -1505,7 +1547,8 @@ def conv_launch_f8(x8: torch.Tensor, w8: torch.Tensor, w_scale: torch.Tensor, x_
     p = L.SpConvParams()
     p.x, p.w, p.bias = x8.data_ptr(), w8.data_ptr(), (bias.data_ptr() if bias is not None else None)
     p.y = y.data_ptr() if y is not None else None
-    p.n, p.h, p.w_, p.cin_p, p.cout, p.ldy, p.ksize, p.act, p.dtype = n, h, w, cin_p, cout, cout, 3, act, L.SP_F8
+    p.n, p.h, p.w_, p.cin_p, p.cout, p.ldy, p.ksize, p.act = n, h, w, cin_p, cout, cout, 3, act
+    p.dtype = L.SP_F8_F16 if compute_dtype() == torch.float16 else L.SP_F8       # e4m3 operands; 16-bit outputs in the storage type
     p.pool2 = pool2
     p.x_scale, p.w_scale = x_scale.data_ptr(), w_scale.data_ptr()
     p.y8 = y8.data_ptr() if y8 is not None else None

@@ -71,7 +71,7 @@ def _conv_case(dt, n, cin, cout, k, h, w, act, res, mask, pool2, bias, up, ldy=N
 
 
 def _wgrad_case(dt, n, cin, cout, k, h, w, up):
-    spd = L.SP_F32 if dt == torch.float32 else L.SP_BF16
+    spd = ops.sp_dtype(dt)
     pad = 4 if dt == torch.float32 else 8
     x = ops.nhwc_empty(n, cin, h, w, dt, 'cuda').normal_()
     cp = (cout + pad - 1) // pad * pad
