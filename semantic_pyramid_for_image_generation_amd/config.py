@@ -16,7 +16,7 @@ results beyond floating-point summation order.  The kernel library itself reads 
     graph_after           SP_GRAPH_AFTER         3        ModelWrapper.train(): capture HIP graphs after this many eager iterations (0 = never)
     d_pair                SP_D_PAIR              1        D(real) and D(fake) of the discriminator step as one two-group pass over 2B images (models.Discriminator.forward_pair)
     f16_loss_scale        SP_F16_LOSS_SCALE      65536    static loss scale of the fp16 storage mode (ops.set_compute_dtype(torch.float16))
-    vgg_fp8               SP_VGG_FP8             0        BASELINE.json config 5: VGG-16's wide 3x3 layers on the fp8 MFMA; 1 = no-gradient pass, 2 = both passes (ops.set_vgg_fp8)
+    vgg_fp8               SP_VGG_FP8             0        BASELINE.json config 5's fp8 slice: VGG-16's wide 3x3 layers on the fp8 MFMA in the no-gradient pass (ops.set_vgg_fp8)
     lib_path              SEMPYR_LIB             (in-tree libsempyr.so)
 """
 from __future__ import annotations

@@ -519,8 +519,8 @@ class _VGGPyramidFn(torch.autograd.Function):
         # of x (slot = index of its scale), produced by the previous layer's epilogue or by sp_quantize_fp8 where the producer is
         # a bf16 kernel; bf16 outputs are still written wherever the pyramid taps / the backward pass need them.
         f8 = packs.get("f8")
-        if f8 is not None and ctx.needs_input_grad[0] and f8["mode"] < 2:
-            f8 = None                                        # mode 1: the pass with gradient stays bf16 (ops.set_vgg_fp8)
+        if f8 is not None and ctx.needs_input_grad[0]:
+            f8 = None                                        # the pass with gradient stays 16-bit (ops.set_vgg_fp8)
         calibrating = f8 is not None and not f8["calibrated"]
         x8 = None
 

@@ -105,7 +105,7 @@ def _dump(name, rec):
 
 # measured on MI355X (round 4; fp16 storage + fp16 MFMA, fp32 accumulate, loss scale 2^16, vs the fp32 reference goldens):
 #   tag                 worst loss error (relative, floor 2e-2)   worst pixel error   pixel rms    (bf16: 1.3e-3 / 3.3e-2 / 6.3e-3)
-F16_MEASURED = {"step_cf1_b2_seed0": (2.2e-4, 4.6e-3, 7.5e-4), "step_cf4_b4_seed1": (2.2e-4, 4.6e-3, 7.5e-4)}
+F16_MEASURED = {"step_cf1_b2_seed0": (1.7e-4, 3.6e-3, 7.5e-4), "step_cf4_b4_seed1": (2.4e-4, 6.7e-3, 9.7e-4)}
 
 
 @pytest.mark.parametrize("tag", ["step_cf1_b2_seed0", "step_cf4_b4_seed1"])
@@ -147,13 +147,15 @@ def test_f16_gradients_follow_fp32_and_need_the_loss_scale():
         rec["bf16_%s" % key] = {"cos": _cos(a, b), "norm_rel": float(abs(a.norm() - b.norm()) / b.norm())}
     _dump("f16_gradient_fidelity", rec)
     for key in ("d", "g"):
-        assert rec["scaled_" + key]["cos"] >= 0.999, rec
-        assert rec["scaled_" + key]["norm_rel"] <= 2e-2, rec
+        # measured: D cosine 0.999999 / norm 2.3e-4, G cosine 0.99984 / norm 1.0e-4 (bf16: 0.99997 / 1.2e-3 and 0.9978 / 3.1e-3;
+        # fp16 WITHOUT the scale at this batch of 4: G norm error 3.1e-3 - the subnormal range still carries a few bits)
+        assert rec["scaled_" + key]["cos"] >= 0.9995, rec
+        assert rec["scaled_" + key]["norm_rel"] <= 2e-3, rec
         assert rec["scaled_" + key]["cos"] >= rec["bf16_" + key]["cos"] - 1e-4, rec          # never worse than the bf16 mode
 
 
 # fp16 storage + the e4m3 slice of the VGG-16 pyramid (no-gradient pass): BASELINE.json config 5 as built
-F16_FP8_MEASURED = {"step_cf1_b2_seed0": (1.4e-2, 0.17, 0.031)}
+F16_FP8_MEASURED = {"step_cf1_b2_seed0": (9.3e-3, 0.182, 0.0294)}
 
 
 def test_config5_f16_with_fp8_vgg_slice_restated_tolerance():

@@ -118,21 +118,38 @@ def test_fp8_partial_co_tile_repeated_launches(case):
         assert float((y.float() - ref).abs().max() / ref.abs().max()) <= 6e-3, rep
 
 
-# measured on MI355X (scratch/measure_f8_grad.py, two golden batches): reconstruction loss value and its gradient w.r.t. the image
-#   mode             loss rel. error   gradient cosine with fp32   gradient rel-L2
-#   bf16 (no fp8)    4e-4              0.84 - 0.86                  0.53 - 0.55     (sign-like L1 loss + ReLU / max-pool routing:
-#   fp8 mode 1       6 - 12 %          0.45 - 0.48                  1.02 - 1.07      already bf16 storage moves this gradient)
-#   fp8 mode 2       2 - 5 %           0.18 - 0.24                  1.23 - 1.29
-GRAD_MEASURED = {1: (0.12, 0.45, 1.07), 2: (0.05, 0.18, 1.29)}
+# measured on MI355X (two golden batches): reconstruction loss value and its gradient w.r.t. the image, against the fp32 oracle
+#   storage / slice        loss rel. error   gradient cosine with fp32   gradient rel-L2
+#   bf16                   4e-4              0.84 - 0.86                  0.53 - 0.55     (sign-like L1 loss + ReLU / max-pool routing:
+#   bf16 + fp8 slice       6 - 12 %          0.45 - 0.48                  1.02 - 1.07      already bf16 storage moves this gradient)
+#   fp16 / fp16 + slice    measured by the test below and written to gpurun_out/fp8_gradient_rule.json
+# (round 3's "mode 2" - e4m3 in the pass WITH gradient: cosine 0.18 - was removed from the product)
+GRAD_MEASURED = (0.12, 0.45, 1.07)
 
 
-@pytest.mark.parametrize("mode", [1, 2])
-def test_fp8_vgg_pyramid_vs_oracle_restated_tolerance(mode):
-    """The seven pyramid taps of the fp8 passes against the fp32 oracle (bound: 2x the measured rel-L2 of every tap) and the
-    reconstruction loss of lossfunction.py:31-68 with its gradient w.r.t. the image (bounds from the measured figures above:
-    loss 2x, cosine >= 2/3 of the measured one, rel-L2 <= 1.25x - the gradient is the honest weak spot of an fp8 perceptual
-    network and the numbers say so).  mode 1: fp8 in the no-gradient pass only; mode 2: both passes.  Call 1 calibrates the
-    activation scales in bf16, calls 2-3 run on delayed scales."""
+def _rec_gradient(dtype, fp8, images, masks, Vsd):
+    ops.set_compute_dtype(dtype)
+    ops.set_vgg_fp8(1 if fp8 else 0)
+    V = sp.VGG16()
+    V.load_state_dict(Vsd)
+    V.cuda().eval()
+    loss_fn = sp.SemanticReconstructionLoss()
+    for _ in range(3):                                  # call 1 calibrates the activation scales in 16 bit, calls 2-3 run on delayed scales
+        with torch.no_grad():
+            real = V(images.flip(0).cuda())
+        x = images.cuda().requires_grad_(True)
+        feats = V(x)
+        loss = loss_fn(real, feats, [m.cuda() for m in masks])
+        loss.backward()
+    if fp8:
+        assert V._packs["f8"]["calibrated"]
+    return real, float(loss), x.grad.float().cpu()
+
+
+def test_fp8_vgg_pyramid_vs_oracle_restated_tolerance():
+    """The seven pyramid taps of the fp8 pass against the fp32 oracle (bound: 2x the measured rel-L2 of every tap) and the
+    reconstruction loss of lossfunction.py:31-68 with its gradient w.r.t. the image (loss 2x measured, cosine >= 2/3 of the
+    measured one, rel-L2 <= 1.25x)."""
     meta, _ = gu.load("step_cf1_b2_seed0")
     _, _, Vsd = gu.synth_states(meta)
     images, _, masks = gu.golden_batches(2, 5)[0]
@@ -140,36 +157,57 @@ def test_fp8_vgg_pyramid_vs_oracle_restated_tolerance(mode):
     with torch.no_grad():
         real_ref = O.vgg16_forward(oV, images.flip(0))
     img_ref = images.clone().requires_grad_(True)
-    fr = O.vgg16_forward(oV, img_ref)
-    loss_ref = O.semantic_reconstruction_loss(real_ref, fr, masks)
+    loss_ref = O.semantic_reconstruction_loss(real_ref, O.vgg16_forward(oV, img_ref), masks)
     loss_ref.backward()
-    ops.set_compute_dtype(torch.bfloat16)
-    ops.set_vgg_fp8(mode)
-    V = sp.VGG16()
-    V.load_state_dict(Vsd)
-    V.cuda().eval()
-    loss_fn = sp.SemanticReconstructionLoss()
-    for _ in range(3):
-        with torch.no_grad():
-            real = V(images.flip(0).cuda())
-        x = images.cuda().requires_grad_(True)
-        feats = V(x)
-        loss = loss_fn(real, feats, [m.cuda() for m in masks])
-        loss.backward()
-    assert V._packs["f8"]["calibrated"] and V._packs["f8"]["mode"] == mode
-    fp8_taps, refs = (feats, fr) if mode == 2 else (real, real_ref)
-    errs = [float((f.detach().float().cpu() - r.detach()).norm() / r.detach().norm()) for f, r in zip(fp8_taps, refs)]
-    print("fp8 mode %d taps rel-L2 %s" % (mode, " ".join("%.4f" % e for e in errs)))
+    real, loss, g = _rec_gradient(torch.bfloat16, True, images, masks, Vsd)
+    errs = [float((f.detach().float().cpu() - r.detach()).norm() / r.detach().norm()) for f, r in zip(real, real_ref)]
+    print("fp8 taps rel-L2 %s" % " ".join("%.4f" % e for e in errs))
     for i, err in enumerate(errs):
         assert err <= 2 * TAP_MEASURED[i], (i, err)
     assert max(errs[1:]) > 0.02, "the e4m3 path did not run (errors look like bf16)"
-    g, r = x.grad.float().cpu(), img_ref.grad
-    lerr = abs(float(loss) - float(loss_ref)) / float(loss_ref)
+    r = img_ref.grad
+    lerr = abs(loss - float(loss_ref)) / float(loss_ref)
     cos = float((g * r).sum() / (g.norm() * r.norm()))
     rel = float((g - r).norm() / r.norm())
-    print("fp8 mode %d rec loss rel err %.4f, gradient cosine %.4f rel-L2 %.4f" % (mode, lerr, cos, rel))
-    m_loss, m_cos, m_rel = GRAD_MEASURED[mode]
-    assert lerr <= 2 * m_loss and cos >= m_cos * 2 / 3 and rel <= 1.25 * m_rel, (mode, lerr, cos, rel)
+    print("fp8 slice: rec loss rel err %.4f, gradient cosine %.4f rel-L2 %.4f" % (lerr, cos, rel))
+    m_loss, m_cos, m_rel = GRAD_MEASURED
+    assert lerr <= 2 * m_loss and cos >= m_cos * 2 / 3 and rel <= 1.25 * m_rel, (lerr, cos, rel)
+
+
+def test_fp8_slice_is_held_to_the_gradient_rule():
+    """A bound that can fail (round-3 VERDICT: the old bounds accepted anything that was not anti-correlated).  RULE: a layer set may
+    run in e4m3 by default only if the reconstruction-loss gradient w.r.t. the image keeps a cosine with the fp32 gradient of at
+    least 0.9 x the cosine of the plain 16-bit storage it replaces; otherwise those layers stay 16-bit and the slice is an opt-in
+    measurement mode.  The test measures all four (bf16, fp16, each with the slice), records them, and asserts the product's
+    default against the rule - today the slice does NOT meet it (e4m3's 4 significant bits on random-sign dot products: 4-8 %
+    noise per tap), so config.CFG.vgg_fp8 must default to 0 and fp16 storage alone is what BASELINE config 5 runs as."""
+    import json
+    import os
+    from semantic_pyramid_for_image_generation_amd.config import Config
+    meta, _ = gu.load("step_cf1_b2_seed0")
+    _, _, Vsd = gu.synth_states(meta)
+    images, _, masks = gu.golden_batches(2, 5)[0]
+    oV = O.make_state(Vsd, frozen=True)
+    with torch.no_grad():
+        real_ref = O.vgg16_forward(oV, images.flip(0))
+    img_ref = images.clone().requires_grad_(True)
+    O.semantic_reconstruction_loss(real_ref, O.vgg16_forward(oV, img_ref), masks).backward()
+    r = img_ref.grad
+    rec = {}
+    for name, dtype, fp8 in (("bf16", torch.bfloat16, False), ("bf16+fp8", torch.bfloat16, True), ("fp16", torch.float16, False),
+                             ("fp16+fp8", torch.float16, True)):
+        _, _, g = _rec_gradient(dtype, fp8, images, masks, Vsd)
+        rec[name] = float((g * r).sum() / (g.norm() * r.norm()))
+    print("reconstruction-loss gradient cosine with fp32: %s" % json.dumps(rec))
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        json.dump(rec, open(os.path.join("gpurun_out", "fp8_gradient_rule.json"), "w"))
+    except OSError:
+        pass
+    assert rec["fp16"] >= 0.97 and rec["fp16"] >= rec["bf16"], rec              # 16-bit storage itself: fp16 is the better of the two
+    for base in ("bf16", "fp16"):
+        meets = rec[base + "+fp8"] >= 0.9 * rec[base]
+        assert meets or Config().vgg_fp8 == 0, ("the fp8 slice is on by default but fails the gradient rule", rec)
 
 
 def test_fp8_mode_train_step_vs_reference_golden():
@@ -177,7 +215,7 @@ def test_fp8_mode_train_step_vs_reference_golden():
     meta, arr = gu.load("step_cf1_b2_seed0")
     Gsd, Dsd, Vsd = gu.synth_states(meta)
     ops.set_compute_dtype(torch.bfloat16)
-    ops.set_vgg_fp8(1)                                                     # the recommended form: e4m3 in the no-gradient pass
+    ops.set_vgg_fp8(1)                                                     # e4m3 in the no-gradient pass
     G, D, V = sp.Generator(channels_factor=1), sp.Discriminator(channel_factor=1), sp.VGG16()
     G.load_state_dict(Gsd); D.load_state_dict(Dsd); V.load_state_dict(Vsd)
     G.cuda().train(); D.cuda().train(); V.cuda().eval()
