@@ -566,6 +566,7 @@ def main():
             dist.barrier()
     launch_mode = job.launch_mode
     comm = job.comm_stats() if world > 1 else None
+    grad_bytes = {k: 4 * int(bk.flat.numel()) for k, bk in job.mw._banks.items() if bk.flat is not None}
     rank_elapsed = job.rank_elapsed
     job.close()
     if rank == 0:
@@ -606,6 +607,18 @@ def main():
                 "exposed_ms_g": comm["g"]["exposed_ms"] if comm and "g" in comm else None,
                 "note": "rank 0's events over 5 extra steps: allreduce_ms = first collective start -> last end on the side stream; "
                         "exposed_ms = main-stream wait at the joins (D's join sits behind the generator forward, G's before Adam(G))"}
+            # what to EXPECT, so that a bad curve can be read from the line alone: bytes on the wire and the time a ring all-reduce of them
+            # takes at the xGMI figures of MI355X_MICROARCH.md (7 links x ~153 GB/s per GPU; a ring is bound by ONE link direction per hop:
+            # t = 2 (N - 1) / N x bytes / link_bw); D's reduction hides behind the generator forward (~3 ms), G's is exposed in full
+            mg = line["multi_gpu"]
+            for key, nb in (("d", grad_bytes.get("d")), ("g", grad_bytes.get("g"))):
+                if nb:
+                    mg["grad_bytes_" + key] = nb
+                    mg["expected_ring_ms_" + key] = round(2.0 * (world - 1) / world * nb / 153e9 * 1e3, 3)
+                    ms_meas = mg.get("allreduce_ms_" + key)
+                    if ms_meas:
+                        mg["measured_algbw_gbps_" + key] = round(nb / (ms_meas * 1e-3) / 1e9, 1)
+            mg["expected_exposed_ms_g"] = mg.get("expected_ring_ms_g")
         if probe is not None:
             families, dom, totals, table, rejected = probe
             if rejected is None:
