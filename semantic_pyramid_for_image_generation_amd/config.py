@@ -15,6 +15,7 @@ results beyond floating-point summation order.  The kernel library itself reads 
     pool2_bwd_fused       SP_POOL2_BWD_FUSED     1        pooled gradients read directly by dgrad / weight gradient (no full-resolution tensor)
     graph_after           SP_GRAPH_AFTER         3        ModelWrapper.train(): capture HIP graphs after this many eager iterations (0 = never)
     d_pair                SP_D_PAIR              1        D(real) and D(fake) of the discriminator step as one two-group pass over 2B images (models.Discriminator.forward_pair)
+    side_features         SP_SIDE_FEATURES       0        the generator's masked-feature mappings (and their weight gradients) on a side stream (measured SLOWER: 1 139 vs 1 159 img/s)
     f16_loss_scale        SP_F16_LOSS_SCALE      65536    static loss scale of the fp16 storage mode (ops.set_compute_dtype(torch.float16))
     vgg_fp8               SP_VGG_FP8             0        BASELINE.json config 5's fp8 slice: VGG-16's wide 3x3 layers on the fp8 MFMA in the no-gradient pass (ops.set_vgg_fp8)
     lib_path              SEMPYR_LIB             (in-tree libsempyr.so)
@@ -42,6 +43,7 @@ class Config:
     vgg_fp8: int = 0
     d_pair: bool = True
     f16_loss_scale: float = 65536.0
+    side_features: bool = False
 
     @classmethod
     def from_env(cls) -> "Config":
@@ -49,7 +51,8 @@ class Config:
                    commute_1x1=_flag("SP_COMMUTE_1X1", True), fuse_pool2=_flag("SP_FUSE_POOL2", True),
                    fuse_act_pool=_flag("SP_FUSE_ACT_POOL", True), fuse_bn_upsample=_flag("SP_FUSE_BN_UPSAMPLE", False),
                    pool2_bwd_fused=_flag("SP_POOL2_BWD_FUSED", True), graph_after=int(os.environ.get("SP_GRAPH_AFTER", "3")), vgg_fp8=int(os.environ.get("SP_VGG_FP8", "0")),
-                   d_pair=_flag("SP_D_PAIR", True), f16_loss_scale=float(os.environ.get("SP_F16_LOSS_SCALE", "65536")))
+                   d_pair=_flag("SP_D_PAIR", True), f16_loss_scale=float(os.environ.get("SP_F16_LOSS_SCALE", "65536")),
+                   side_features=_flag("SP_SIDE_FEATURES", False))
 
 
 CFG = Config.from_env()

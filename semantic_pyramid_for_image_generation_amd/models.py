@@ -110,6 +110,11 @@ _FUSE_ACT_POOL = CFG.fuse_act_pool
 # SLOWER than the two kernels (897 vs 932 img/s: every source pixel is normalised by four output pixels and the class-gathered
 # affine is re-read per output vector), so it is off by default; the operator stays for A/B runs.
 _FUSE_BN_UPSAMPLE = CFG.fuse_bn_upsample
+# The generator's masked-feature mappings on a side stream (Generator._map_features_ahead; a parallel branch of the captured graph):
+# built in round 4 and measured SLOWER - 1 139 vs 1 159 img/s, same box, alternating runs: the convolution kernels are persistent
+# (one block per CU walks the work items), so a second kernel on some CUs delays those blocks and with them the whole launch.
+# Off by default; SP_SIDE_FEATURES=1 for A/B runs.
+_SIDE_FEATURES = CFG.side_features
 
 
 def init_weights(module: nn.Module) -> None:
@@ -209,7 +214,9 @@ class GeneratorResidualBlock(nn.Module):
         self.residual_mapping = nn.Sequential(nn.UpsamplingBilinear2d(scale_factor=2), SNConv2d(in_channels, out_channels, 1))
         self.masked_feature_mapping = SNConv2d(feature_channels, out_channels, 3)
 
-    def forward(self, input: torch.Tensor, masked_features: torch.Tensor, class_id: torch.Tensor) -> torch.Tensor:
+    def forward(self, input: torch.Tensor, masked_features: torch.Tensor, class_id: torch.Tensor, mapped=None) -> torch.Tensor:
+        """mapped: the output of masked_feature_mapping computed ahead of time (Generator's side stream), as a zero-argument
+        callable that makes it visible to the current stream and returns it."""
         cls = _class_index(class_id)
         if _FUSE_BN_UPSAMPLE:
             h = self.main_block[3](self.main_block[0](input, cls, ACT_LRELU, upsample=True))     # CBN + LeakyReLU + bilinear x2 in one pass
@@ -221,7 +228,7 @@ class GeneratorResidualBlock(nn.Module):
             r = ops.upsample2(self.residual_mapping[1](input))
         else:
             r = self.residual_mapping[1](ops.upsample2(input))
-        f = self.masked_feature_mapping(masked_features)
+        f = mapped() if mapped is not None else self.masked_feature_mapping(masked_features)
         return self.main_block[6](h, ACT_NONE, r, f)                  # (main + residual) + features in the epilogue
 
 
@@ -234,10 +241,10 @@ class LinearBlock(nn.Module):
         self.masked_feature_mapping = SNLinear(feature_size, out_features)
 
     def forward(self, input: torch.Tensor, masked_features: torch.Tensor, act_out: int = ACT_NONE,
-                input_is_activated: bool = False) -> torch.Tensor:
+                input_is_activated: bool = False, mapped=None) -> torch.Tensor:
         if not input_is_activated:
             input = ops.activation(input, ACT_LRELU)
-        mapped = self.masked_feature_mapping(masked_features)
+        mapped = mapped() if mapped is not None else self.masked_feature_mapping(masked_features)
         return self.main_block[1](input, act_out, mapped)
 
 
@@ -325,6 +332,41 @@ class Generator(nn.Module):
         self._bank = ops.SpectralNormBank(_collect_sn(self, no_dgrad=("masked_feature_mapping",)), _non_sn_params(self))
         self._bn_list = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
         self._nbt_flat = None
+        self._side_streams = {}
+
+    def _map_features_ahead(self, features, masks):
+        """The seven masked-feature mappings (models.py:78-94: mask * feature [cat mask] -> spectral-norm linear / 3x3 convolution)
+        depend on the frozen VGG-16 pyramid only, not on the activations of the generator: they are enqueued on a SIDE STREAM at the
+        start of the forward pass and joined (an event per mapping) where a block adds its mapping in.  Their kernels - and, since
+        autograd runs a node's backward on the stream of its forward, their weight-gradient kernels - then overlap the low-resolution
+        stages of the main path, whose launches are too small to fill 256 CUs on their own (4x4 ... 32x32 maps).  Under HIP-graph
+        capture the side stream becomes a parallel branch of the graph.  Returns {pyramid depth: callable -> mapped tensor}."""
+        dev = features[0].device
+        if dev.type != "cuda":
+            return {}
+        main = torch.cuda.current_stream(dev)
+        side = self._side_streams.get(dev)
+        if side is None:
+            side = self._side_streams[dev] = torch.cuda.Stream(dev)
+        side.wait_stream(main)                       # the features / masks / packed weights were produced on the main stream
+        out = {}
+        depth = len(features) - 1
+        with torch.cuda.stream(side):
+            jobs = [(self.linear_block_1, True), (self.linear_block_2, True)] + [(m, False) for m in self.main_path
+                                                                                 if isinstance(m, GeneratorResidualBlock)]
+            for block, is_linear in jobs:
+                src = ops.mask_mul_2d(features[depth], masks[depth]) if is_linear else ops.mask_concat(features[depth], masks[depth])
+                f = block.masked_feature_mapping(src)
+                ev = torch.cuda.Event()
+                ev.record(side)
+
+                def visible(f=f, ev=ev, main=main):
+                    torch.cuda.current_stream(f.device).wait_event(ev)
+                    f.record_stream(torch.cuda.current_stream(f.device))     # allocated on the side stream, consumed (and freed) on this one
+                    return f
+                out[depth] = visible
+                depth -= 1
+        return out
 
     def _tick_batch_counters(self) -> None:
         """num_batches_tracked += 1 for every BatchNorm layer with one launch: the counters are 0-dim views of one int64
@@ -350,11 +392,14 @@ class Generator(nn.Module):
                 _COUNTERS_TICKED[0] = True
             cls = _class_index(class_id)
             depth = len(features) - 1
+            mapped = self._map_features_ahead(features, masks) if _SIDE_FEATURES else {}
             # the latent's requires_grad (model_wrapper.py:148) is a dead gradient: detach
             x = self.linear_layer(ops.as_rows(input.detach(), dt), ACT_LRELU)
-            x = self.linear_block_1(x, ops.mask_mul_2d(features[depth], masks[depth]), ACT_LRELU, True)
+            x = self.linear_block_1(x, None if depth in mapped else ops.mask_mul_2d(features[depth], masks[depth]), ACT_LRELU, True,
+                                    mapped.get(depth))
             depth -= 1
-            x = self.linear_block_2(x, ops.mask_mul_2d(features[depth], masks[depth]), ACT_LRELU, True)
+            x = self.linear_block_2(x, None if depth in mapped else ops.mask_mul_2d(features[depth], masks[depth]), ACT_LRELU, True,
+                                    mapped.get(depth))
             depth -= 1
             x = ops.rows_to_nhwc(x, x.shape[1] // 16, 4, 4)            # view(B, -1, 4, 4) of the NCHW reference
             x = self.convolution_layer[1](x)
@@ -362,7 +407,7 @@ class Generator(nn.Module):
                 if isinstance(layer, SelfAttention):
                     x = layer(x)
                 else:
-                    x = layer(x, ops.mask_concat(features[depth], masks[depth]), cls)
+                    x = layer(x, None if depth in mapped else ops.mask_concat(features[depth], masks[depth]), cls, mapped.get(depth))
                     depth -= 1
             fb = self.final_block
             bn = fb[1]

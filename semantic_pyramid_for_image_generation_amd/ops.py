@@ -510,6 +510,10 @@ class SpectralNormBank:
         weights = [m.weight_orig for m, _, _ in self.specs]
         self.handles = None
         if torch.is_grad_enabled() and any(w.requires_grad for w in weights):
+            # the gradient arena is zero-filled NOW, on the stream the forward starts on: weight-gradient kernels of layers whose
+            # forward ran on a side stream accumulate into it from that stream (models.Generator._map_features_ahead), and every
+            # stream the forward forks waits for this one first
+            call.grad_arena()
             hs = []
             for g, (lo, hi) in enumerate(self.groups):
                 hs.extend(_SNBankFn.apply(call, g, *weights[lo:hi]))
