@@ -403,10 +403,18 @@ int sp_quantize_fp8(const void* x, void* q, int64_t numel, const float* inv_scal
 int sp_pack_weight_fp8(const float* w, int32_t cout, int32_t cin, int32_t cin_p, void* out, float* w_scale, sp_stream_t stream);
 int sp_fp8_update_scales(float* amax, float* scale, float* inv_scale, int32_t n, float margin, sp_stream_t stream);
 
+/* kornia.normalize_min_max(image[None], min_val=-1, max_val=1) of the reference's data pipeline (/root/reference/data.py:53), for a
+ * whole batch on the device: y = (hi - lo) * (x - min) / (max - min + eps) + lo in fp32, operation for operation as torch evaluates
+ * it (bit-identical).  x, y: [batch][channels][hw] contiguous fp32 (NCHW, what TVF.to_tensor yields); per_channel != 0: min / max per
+ * (image, channel) plane - kornia's definition (x.view(B, C, -1).min(-1)); 0: per image over all channels.  eps: kornia uses 1e-6. */
+int sp_minmax_normalize(const float* x, float* y, int32_t batch, int32_t channels, int64_t hw, float lo, float hi, float eps,
+                        int32_t per_channel, sp_stream_t stream);
+
 /* A batch of training masks generated on the device: misc.get_masks_for_training
  * (/root/reference/misc.py:13-68) for every sample of the batch in one launch - stage ~ choice([0..6, 0, 1]) counted from the deep
  * end, with probability p_random_mask (reference: 0.3) and 0 < stage < 6 a 0/1 shape map on the next finer level expanded
- * nearest-neighbour to all finer levels, everything deeper than the stage zero, exact 0.0f / 1.0f.  The seven outputs are the
+ * nearest-neighbour to all finer levels, everything deeper than the stage zero, exact 0.0f / 1.0f.  The shape map holds 1 - 4
+ * shapes of the four kinds skimage.draw.random_shapes draws (rectangle, circle, triangle, ellipse), each inside a random bounding box.  The seven outputs are the
  * reference's list order, fp32, [batch][1][S][S] contiguous / [batch][4096] / [batch][365].  All randomness is integer
  * arithmetic on splitmix64(seed, sample, draw): the same (seed, batch) gives the same masks on every device, and the oracle
  * restates the generator bit for bit (tests/test_gpu_next_rows.py). */

@@ -493,15 +493,29 @@ def training_masks(batch: int, seed: int, p_random_mask: float = 0.3) -> List[to
                 w = lo + _draw(seed, b, 4 + 4 * k) % (base - lo + 1)
                 y0 = _draw(seed, b, 5 + 4 * k) % (base - h + 1)
                 x0 = _draw(seed, b, 6 + 4 * k) % (base - w + 1)
-                rects.append((y0, x0, h, w))
+                rects.append((y0, x0, h, w, _draw(seed, b, 19 + k) % 4))
         for idx in range(7):
             if idx == stage:
                 levels[idx][b] = 1.0
             elif idx > stage and spatial:
                 side = sides[idx]
                 shape_map = torch.ones(base, base)
-                for y0, x0, h, w in rects:
-                    shape_map[y0:y0 + h, x0:x0 + w] = 0.0
+                for y0, x0, h, w, kind in rects:
+                    # kinds of skimage.draw.random_shapes (misc.py:37): 0 rectangle, 1 circle, 2 triangle, 3 ellipse - inside the box,
+                    # on pixel centres, integer arithmetic (csrc/eltwise.hip: training_masks_kernel)
+                    dy = torch.arange(h, dtype=torch.int64)[:, None]
+                    dx = torch.arange(w, dtype=torch.int64)[None, :]
+                    ey, ex = 2 * dy + 1 - h, 2 * dx + 1 - w
+                    if kind == 0:
+                        hit = torch.ones(h, w, dtype=torch.bool)
+                    elif kind == 1:
+                        hit = ey * ey + ex * ex <= min(h, w) ** 2
+                    elif kind == 2:
+                        hit = ex.abs() * 2 * h <= w * (2 * dy + 1)
+                    else:
+                        hit = ey * ey * w * w + ex * ex * h * h <= h * h * w * w
+                    box = shape_map[y0:y0 + h, x0:x0 + w]
+                    box[hit] = 0.0
                 src = (torch.arange(side) * base) // side
                 levels[idx][b] = shape_map[src][:, src].reshape(-1)
     out = []

@@ -380,10 +380,15 @@ extern "C" int sp_channel_sum(const void* x, int32_t ld, int64_t pixels, int32_t
 //   draw 0: stage = [0,1,2,3,4,5,6,0,1][r % 9]                (misc.py:28: random.choice(list(range(7)) + [0, 1]), deep end first)
 //   draw 1: spatial = (r >> 40) < p_random * 2^24  and  0 < stage < 6        (misc.py:32-34)
 //   draw 2: number of shapes 1 + r % 4                                          (misc.py:38-39: min_shapes 1, max_shapes 4)
-//   draws 3 + 4k .. 6 + 4k (shape k): h = lo + r % (base - lo + 1), w likewise, y0 = r % (base - h + 1), x0 likewise, on the
-//            level just finer than the stage (side `base`, lo = min(8, base / 2): misc.py:37-41); axis-aligned rectangles
-//            stand in for skimage's random shapes (not available offline; the mask contract - zeros inside shapes, ones
-//            outside, nearest-neighbour expansion to every finer level, misc.py:45,55 - is the reference's)
+//   draws 3 + 4k .. 6 + 4k (shape k): bounding box h = lo + r % (base - lo + 1), w likewise, y0 = r % (base - h + 1), x0 likewise,
+//            on the level just finer than the stage (side `base`, lo = min(8, base / 2): misc.py:37-41)
+//   draw 19 + k: kind of shape k = r % 4 - rectangle, circle, triangle, ellipse, the four kinds skimage.draw.random_shapes chooses
+//            from (misc.py:37; skimage itself is not available offline, so its generator cannot be restated - the mask CONTRACT is
+//            the reference's: zeros inside shapes, ones outside, nearest-neighbour expansion to every finer level, misc.py:45,55).
+//            Inside its bounding box (dy, dx from the box corner, pixel centres, all in integers so the oracle restates it exactly):
+//            rectangle: every pixel;  ellipse (inscribed): (2dy+1-h)^2 w^2 + (2dx+1-w)^2 h^2 <= h^2 w^2;
+//            circle (inscribed, diameter d = min(h, w), centred): (2dy+1-h)^2 + (2dx+1-w)^2 <= d^2;
+//            triangle (apex top centre, base = bottom edge): |2dx+1-w| * 2h <= w * (2dy+1)
 // Level idx (0 = the 365-vector ... 6 = 128 x 128): ones where idx == stage, zeros where idx < stage; idx > stage: zeros, or
 // with `spatial` the shape map read through the nearest-neighbour index i * base / side.  Values are exact 0.0f / 1.0f.
 // ------------------------------------------------------------------------------------------------------------
@@ -408,7 +413,7 @@ static __global__ __launch_bounds__(256) void training_masks_kernel(sp_mask_ptrs
     const bool spatial = (unsigned)(sp_draw(seed, b, 1) >> 40) < thresh24 && stage > 0 && stage < 6;
     const int base = side_of[stage + 1 > 6 ? 6 : stage + 1];
     const int lo = base / 2 < 8 ? base / 2 : 8;
-    int nrect = 0, ry[4], rx[4], rh[4], rw[4];
+    int nrect = 0, ry[4], rx[4], rh[4], rw[4], kind[4];
     if (spatial) {
         nrect = 1 + (int)(sp_draw(seed, b, 2) % 4);
         for (int k = 0; k < 4; ++k) {
@@ -416,8 +421,18 @@ static __global__ __launch_bounds__(256) void training_masks_kernel(sp_mask_ptrs
             rw[k] = lo + (int)(sp_draw(seed, b, 4 + 4 * k) % (unsigned)(base - lo + 1));
             ry[k] = (int)(sp_draw(seed, b, 5 + 4 * k) % (unsigned)(base - rh[k] + 1));
             rx[k] = (int)(sp_draw(seed, b, 6 + 4 * k) % (unsigned)(base - rw[k] + 1));
+            kind[k] = (int)(sp_draw(seed, b, 19 + k) % 4);
         }
     }
+    auto inside = [&](int k, int y, int x) {
+        const int dy = y - ry[k], dx = x - rx[k], h = rh[k], w = rw[k];
+        if (dy < 0 || dy >= h || dx < 0 || dx >= w) return false;
+        const long long ey = 2 * dy + 1 - h, ex = 2 * dx + 1 - w;
+        if (kind[k] == 0) return true;                                                              // rectangle
+        if (kind[k] == 1) { const long long d = h < w ? h : w; return ey * ey + ex * ex <= d * d; }   // circle
+        if (kind[k] == 2) return (ex < 0 ? -ex : ex) * 2 * h <= (long long)w * (2 * dy + 1);        // triangle
+        return ey * ey * w * w + ex * ex * h * h <= (long long)h * h * w * w;                        // ellipse
+    };
     for (int idx = 0; idx < 7; ++idx) {
         float* dst = out.m[6 - idx] + (long)b * numel_of[idx];
         const int n = numel_of[idx], side = side_of[idx];
@@ -429,10 +444,45 @@ static __global__ __launch_bounds__(256) void training_masks_kernel(sp_mask_ptrs
         for (int i = threadIdx.x; i < n; i += 256) {
             const int y = (i / side) * base / side, x = (i % side) * base / side;
             bool hit = false;
-            for (int k = 0; k < nrect; ++k) hit |= y >= ry[k] && y < ry[k] + rh[k] && x >= rx[k] && x < rx[k] + rw[k];
+            for (int k = 0; k < nrect; ++k) hit |= inside(k, y, x);
             dst[i] = hit ? 0.f : 1.f;
         }
     }
+}
+
+// kornia.normalize_min_max(image, -1, 1) of the data pipeline (/root/reference/data.py:53):
+//   y = (hi - lo) * (x - min) / (max - min + eps) + lo,  min / max over one plane (per_channel) or over the whole image.
+// One block per (image, channel) or per image; every operation in the reference's order and in fp32: bit-identical to torch.
+static __global__ __launch_bounds__(256) void minmax_normalize_kernel(const float* __restrict__ x, float* __restrict__ y, long plane, int planes,
+                                                                      float lo, float hi, float eps) {
+    __shared__ float smin[4], smax[4];
+    const long n = plane * planes;
+    const float* src = x + (long)blockIdx.x * n;
+    float* dst = y + (long)blockIdx.x * n;
+    float mn = INFINITY, mx = -INFINITY;
+    for (long i = threadIdx.x; i < n; i += 256) { const float v = src[i]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o, 64)); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = mn; smax[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    mn = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
+    mx = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+    const float range = hi - lo;
+    const float den = (mx - mn) + eps;
+    for (long i = threadIdx.x; i < n; i += 256) {
+        const float t = range * (src[i] - mn);
+        dst[i] = __fadd_rn(__fdiv_rn(t, den), lo);          // explicit roundings: no contraction into an fma, IEEE division
+    }
+}
+
+extern "C" int sp_minmax_normalize(const float* x, float* y, int32_t batch, int32_t channels, int64_t hw, float lo, float hi, float eps,
+                                   int32_t per_channel, sp_stream_t stream) {
+    SP_CHECK_ARG(x && y && batch > 0 && channels > 0 && hw > 0, "sp_minmax_normalize: bad args");
+    const int blocks = per_channel ? batch * channels : batch;
+    hipLaunchKernelGGL(minmax_normalize_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, y, (long)hw,
+                       per_channel ? 1 : channels, lo, hi, eps);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
 }
 
 extern "C" int sp_training_masks(float* m128, float* m64, float* m32, float* m16, float* m8, float* m4096, float* m365,

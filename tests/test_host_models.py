@@ -111,7 +111,38 @@ def test_device_mask_generator_follows_the_contract():
             src = m[i - 1]
             for j in range(i - 1):                                  # ... as the nearest-neighbour upsampling of the coarsest one
                 assert torch.equal(m[j], F.interpolate(src[None], size=m[j].shape[1:], mode="nearest")[0])
-            assert float(src.min()) == 0.0                          # at least one rectangle
+            assert float(src.min()) == 0.0                          # at least one shape
     freq = stage_hist / 512
     assert abs(float(freq[6]) - 2 / 9) < 0.07 and abs(float(freq[5]) - 2 / 9) < 0.07 and abs(float(freq[0]) - 1 / 9) < 0.06
     assert 0.08 < n_spatial / 512 < 0.32
+
+
+def test_device_mask_shapes_are_the_four_kinds():
+    """Row f1 leftovers (round-3 VERDICT): the shape map holds rectangles, circles, triangles and ellipses - the four kinds
+    skimage.draw.random_shapes draws (misc.py:37) - each kind about a quarter of the shapes; a circle / triangle / ellipse covers
+    less of its bounding box than the rectangle (pi/4, ~1/2, pi/4), every shape at least one pixel.  Checked on the oracle's
+    bit-exact restatement of the kernel."""
+    from oracle import sempyr_oracle as O
+    kinds = [0, 0, 0, 0]
+    fill = [[], [], [], []]
+    seed, n_samples = 11, 2048
+    masks = O.training_masks(n_samples, seed, 1.0)
+    for b, (stage, spatial) in enumerate(O.training_mask_decisions(n_samples, seed, 1.0)):
+        if not spatial:
+            continue
+        base = [1, 1, 8, 16, 32, 64, 128][min(stage + 1, 6)]
+        lo = min(8, base // 2)
+        if 1 + O._draw(seed, b, 2) % 4 != 1:
+            continue                                        # single-shape samples: the covered area is that shape's area
+        h = lo + O._draw(seed, b, 3) % (base - lo + 1)
+        w = lo + O._draw(seed, b, 4) % (base - lo + 1)
+        kind = O._draw(seed, b, 19) % 4
+        kinds[kind] += 1
+        covered = float((masks[6 - (stage + 1)][b] == 0).sum())          # the level just finer than the stage holds the shape map itself
+        assert covered >= 1
+        fill[kind].append(covered / (h * w))
+    n = sum(kinds)
+    assert n > 250 and all(abs(k / n - 0.25) < 0.08 for k in kinds), kinds
+    mean = [sum(f) / len(f) for f in fill]
+    # rectangle: its box; inscribed ellipse: pi / 4; triangle: 1 / 2; circle of diameter min(h, w): pi / 4 of the SMALLER square
+    assert mean[0] == 1.0 and 0.4 < mean[1] < 0.8 and 0.4 < mean[2] < 0.6 and 0.72 < mean[3] < 0.88, mean
