@@ -292,6 +292,21 @@ int sp_bn_backward(const void* dy, const void* x, void* dx, int32_t n, int64_t h
                    int32_t act, float* partials, float* c_tmp, float* dgamma, float* dbeta, float* demb,
                    int32_t num_classes, int32_t dtype, sp_stream_t stream);
 
+/* BatchNorm (+ activation) of u = bilinear x2 (align_corners=True) of a stored tensor x [n][h][w][c], without materialising u: the
+ * generator's final block, UpsamplingBilinear2d -> BatchNorm2d -> LeakyReLU (models.py:52-54).  Same statistics / running-stat /
+ * gradient semantics as sp_bn_stats / sp_bn_apply / sp_bn_backward applied to u [n][2h][2w][c] (u takes the storage type's rounding,
+ * as if it had been written); y and dy are [n][2h][2w][c]; sp_bn_backward_up2 writes du = d loss / d u [n][2h][2w][c] - the caller
+ * folds it back with sp_upsample2_bwd.  partials: 1024*2*c floats, c_tmp: 2*c floats of scratch.  c / (16-byte group) <= 256. */
+int sp_bn_stats_up2(const void* x, int32_t n, int32_t h, int32_t w_, int32_t c, float* partials, float eps, float momentum,
+                    float* running_mean, float* running_var, float* mean_out, float* invstd_out, int32_t dtype, sp_stream_t stream);
+int sp_bn_apply_up2(const void* x, void* y, int32_t n, int32_t h, int32_t w_, int32_t c, const float* mean, const float* invstd,
+                    const float* gamma, const float* beta, const float* emb, const int64_t* cls, int32_t act, int32_t dtype,
+                    sp_stream_t stream);
+int sp_bn_backward_up2(const void* dy, const void* x, void* du, int32_t n, int32_t h, int32_t w_, int32_t c, const float* mean,
+                       const float* invstd, const float* gamma, const float* beta, const float* emb, const int64_t* cls,
+                       int32_t act, float* partials, float* c_tmp, float* dgamma, float* dbeta, float* demb, int32_t num_classes,
+                       int32_t dtype, sp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Pooling / resampling (NHWC, c % 4 == 0).
  *   avg-pool 2x2 (models.py:406,451); optional second output y_act = act(y)

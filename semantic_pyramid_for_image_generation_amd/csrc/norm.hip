@@ -204,24 +204,35 @@ __global__ __launch_bounds__(256) void bn_apply_upsample2_kernel(const T* __rest
         const T* r0 = x + ((long)n * H + h0) * W * C + c;
         const T* r1 = x + ((long)n * H + h1) * W * C + c;
         T* yr = y + ((long)n * OH + oh) * OW * C + c;
-#pragma unroll 2
-        for (int ow = blockIdx.x * L.pix_par + L.pl; ow < OW; ow += gridDim.x * L.pix_par) {
-            const float fw = sw * ow;
-            const int w0 = (int)fw;
-            const int w1 = w0 + (w0 < W - 1 ? 1 : 0);
-            const float lw = fw - w0;
-            float v00[V], v01[V], v10[V], v11[V], o[V];
-            VecIO<T, V>::ld(r0 + (long)w0 * C, v00);
-            VecIO<T, V>::ld(r0 + (long)w1 * C, v01);
-            VecIO<T, V>::ld(r1 + (long)w0 * C, v10);
-            VecIO<T, V>::ld(r1 + (long)w1 * C, v11);
+        // a thread produces the four output columns 4q - 3 ... 4q from the THREE source columns 2q - 2 ... 2q they interpolate between
+        // (bn_up2_kernel below explains the pattern): 6 loads and 6 normalisations per 4 outputs instead of 16 each.  Rows are blended
+        // first, then columns: the reference's order up to fp32 rounding.
+        for (int q = blockIdx.x * L.pix_par + L.pl; 4 * q - 3 < OW; q += gridDim.x * L.pix_par) {
+            float t[3][V];
 #pragma unroll
-            for (int r = 0; r < V; ++r) { v00[r] = fmaf(a[r], v00[r], b[r]); v01[r] = fmaf(a[r], v01[r], b[r]); v10[r] = fmaf(a[r], v10[r], b[r]); v11[r] = fmaf(a[r], v11[r], b[r]); }
-            apply_act_vec<V>(v00, act); apply_act_vec<V>(v01, act); apply_act_vec<V>(v10, act); apply_act_vec<V>(v11, act);
+            for (int k = 0; k < 3; ++k) {
+                int col = 2 * q - 2 + k;
+                col = col < 0 ? 0 : (col < W ? col : W - 1);
+                float s0[V], s1[V];
+                VecIO<T, V>::ld(r0 + (long)col * C, s0);
+                VecIO<T, V>::ld(r1 + (long)col * C, s1);
 #pragma unroll
-            for (int r = 0; r < V; ++r)
-                o[r] = (1.f - lh) * ((1.f - lw) * v00[r] + lw * v01[r]) + lh * ((1.f - lw) * v10[r] + lw * v11[r]);
-            VecIO<T, V>::st(yr + (long)ow * C, o);
+                for (int r = 0; r < V; ++r) { s0[r] = fmaf(a[r], s0[r], b[r]); s1[r] = fmaf(a[r], s1[r], b[r]); }
+                apply_act_vec<V>(s0, act); apply_act_vec<V>(s1, act);
+#pragma unroll
+                for (int r = 0; r < V; ++r) t[k][r] = (1.f - lh) * s0[r] + lh * s1[r];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ow = 4 * q - 3 + j;
+                if (ow < 0 || ow >= OW) continue;
+                const int w0 = 2 * q - 2 + (j >> 1);
+                const float lw = ow == 0 ? 0.f : sw * ow - (float)w0;
+                float o[V];
+#pragma unroll
+                for (int r = 0; r < V; ++r) o[r] = (1.f - lw) * t[j >> 1][r] + lw * t[(j >> 1) + 1][r];
+                VecIO<T, V>::st(yr + (long)ow * C, o);
+            }
         }
     }
     }
@@ -378,6 +389,150 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// BatchNorm of a tensor that is the bilinear x2 expansion (align_corners) of a stored one - the generator's final block,
+// UpsamplingBilinear2d -> BatchNorm2d -> LeakyReLU (models.py:52-54) on 64 channels at 256 x 256: the expansion u = up2(x) is never
+// written.  The separate passes move x + 4x (upsample) + 4x (statistics) + 8x (apply) = 17 units of the low-resolution tensor
+// through HBM, these kernels x (statistics) + x + 4x (apply) = 6; the backward reads x instead of u twice.  One kernel body, four
+// modes; every mode walks output rows with four output columns per thread step (8 loads per 4 interpolated vectors).
+//   grid (column slabs, row slabs, samples); a thread keeps one 16-byte channel group (C / V <= 256 groups)
+//   STATS      part[((n * gy + by) * gx + bx)][C][2] = (sum u, sum u^2) of the block's pixels      -> bn_finalize_kernel
+//   APPLY      out = act(a u + b)
+//   BWD_REDUCE part[n][by * gx + bx][C][2] = (sum dz, sum dz xhat), dz = dy act'(z)                 -> bn_bwd_finalize_kernel
+//   BWD_APPLY  out = d loss / d u = invstd (dz scale - c1 - xhat c2)         (sp_upsample2_bwd then folds it back onto x)
+// ------------------------------------------------------------------------------------------------------------------------------
+enum { UP2_STATS = 0, UP2_APPLY = 1, UP2_BWD_REDUCE = 2, UP2_BWD_APPLY = 3 };
+template <typename T, int V, int MODE>
+__global__ __launch_bounds__(256) void bn_up2_kernel(const T* __restrict__ x, int H, int W, int C, const T* __restrict__ dy, T* __restrict__ out,
+                                                     const float* __restrict__ mean, const float* __restrict__ invstd, Affine aff, int act,
+                                                     const float* __restrict__ c1, const float* __restrict__ c2, float* __restrict__ part) {
+    __shared__ float red[(MODE == UP2_STATS || MODE == UP2_BWD_REDUCE) ? 256 * 2 * V : 1];
+    const int OH = 2 * H, OW = 2 * W;
+    const float sh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
+    const float sw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+    const int n = blockIdx.z;
+    const Lay L = make_lay(C / V);
+    const int c = L.cg * V;
+    const bool live = c < C && L.pl < L.pix_par;
+    float acc0[V], acc1[V];
+#pragma unroll
+    for (int r = 0; r < V; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    if (live) {
+        float sc[V], bi[V], mu[V], is[V], k1[V], k2[V], a[V], b[V];
+#pragma unroll
+        for (int r = 0; r < V; ++r) { sc[r] = 1.f; bi[r] = 0.f; mu[r] = 0.f; is[r] = 1.f; k1[r] = 0.f; k2[r] = 0.f; }
+        if constexpr (MODE != UP2_STATS) {
+            aff.template getv<V>(n, c, C, sc, bi);
+            ldv<V>(mean + c, mu); ldv<V>(invstd + c, is);
+        }
+        if constexpr (MODE == UP2_BWD_APPLY) { ldv<V>(c1 + c, k1); ldv<V>(c2 + c, k2); }
+#pragma unroll
+        for (int r = 0; r < V; ++r) { a[r] = sc[r] * is[r]; b[r] = bi[r] - mu[r] * a[r]; }
+        for (int oh = blockIdx.y; oh < OH; oh += gridDim.y) {
+            const float fh = sh * oh;
+            const int h0 = (int)fh;
+            const int h1 = h0 + (h0 < H - 1 ? 1 : 0);
+            const float lh = fh - h0;
+            const T* r0 = x + ((long)n * H + h0) * W * C + c;
+            const T* r1 = x + ((long)n * H + h1) * W * C + c;
+            const long orow = ((long)n * OH + oh) * OW;
+            // output columns 2k + 1 and 2k + 2 both interpolate between source columns k and k + 1 (align_corners: column ow sits at
+            // ow (W - 1) / (2W - 1)), so a thread takes the four outputs 4q - 3 ... 4q from THREE source columns 2q - 2, 2q - 1, 2q
+            // with a fixed pattern - 6 loads per 4 vectors and no per-element selects (the first form, 8 loads and two select chains
+            // per element, was bound by its VALU work: 80 - 110 us per pass on the 256 x 256 layer)
+            for (int q = blockIdx.x * L.pix_par + L.pl; 4 * q - 3 < OW; q += gridDim.x * L.pix_par) {
+                float t[3][V];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    int col = 2 * q - 2 + k;
+                    col = col < 0 ? 0 : (col < W ? col : W - 1);
+                    float s0[V], s1[V];
+                    VecIO<T, V>::ld(r0 + (long)col * C, s0);
+                    VecIO<T, V>::ld(r1 + (long)col * C, s1);
+#pragma unroll
+                    for (int r = 0; r < V; ++r) t[k][r] = (1.f - lh) * s0[r] + lh * s1[r];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ow = 4 * q - 3 + j;
+                    if (ow < 0 || ow >= OW) continue;
+                    const int w0 = 2 * q - 2 + (j >> 1);                       // = floor(ow (W - 1) / (2W - 1)) for ow >= 1
+                    const float lw = ow == 0 ? 0.f : sw * ow - (float)w0;
+                    float u[V];
+#pragma unroll
+                    for (int r = 0; r < V; ++r) u[r] = (1.f - lw) * t[j >> 1][r] + lw * t[(j >> 1) + 1][r];
+                    if constexpr (sizeof(T) == 2) {
+                        // the separate passes stored u in the 16-bit type and normalised THAT: round here too, so that the statistics, the
+                        // output and the backward see one and the same tensor whether or not it is materialised
+#pragma unroll
+                        for (int r = 0; r < V; r += 2) {
+                            const uint32_t w2 = f32x2_to_bf16x2(u[r], u[r + 1]);
+                            u[r] = h16_lo_to_f32(w2);
+                            u[r + 1] = h16_hi_to_f32(w2);
+                        }
+                    }
+                    const long off = (orow + ow) * C + c;
+                    if constexpr (MODE == UP2_STATS) {
+#pragma unroll
+                        for (int r = 0; r < V; ++r) { acc0[r] += u[r]; acc1[r] += u[r] * u[r]; }
+                    } else if constexpr (MODE == UP2_APPLY) {
+#pragma unroll
+                        for (int r = 0; r < V; ++r) u[r] = fmaf(a[r], u[r], b[r]);
+                        apply_act_vec<V>(u, act);
+                        VecIO<T, V>::st(out + off, u);
+                    } else {
+                        float d[V];
+                        VecIO<T, V>::ld(dy + off, d);
+#pragma unroll
+                        for (int r = 0; r < V; ++r) {
+                            const float xh = (u[r] - mu[r]) * is[r];
+                            float dz = d[r];
+                            if (act == SP_ACT_LRELU) dz = (sc[r] * xh + bi[r]) > 0.f ? dz : 0.2f * dz;
+                            if constexpr (MODE == UP2_BWD_REDUCE) { acc0[r] += dz; acc1[r] += dz * xh; }
+                            else d[r] = is[r] * (dz * sc[r] - k1[r] - xh * k2[r]);
+                        }
+                        if constexpr (MODE == UP2_BWD_APPLY) VecIO<T, V>::st(out + off, d);
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (MODE == UP2_STATS || MODE == UP2_BWD_REDUCE) {
+#pragma unroll
+        for (int r = 0; r < V; ++r) { red[threadIdx.x * 2 * V + r] = acc0[r]; red[threadIdx.x * 2 * V + V + r] = acc1[r]; }
+        __syncthreads();
+        if (live && L.pl == 0) {
+            const long prow = ((long)n * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;     // both layouts: sample-major, then the sample's blocks
+            for (int r = 0; r < V; ++r) {
+                float ta = 0.f, tb = 0.f;
+                for (int k = 0; k < L.pix_par; ++k) {
+                    ta += red[(k * L.lanes_per_pix + L.cg) * 2 * V + r];
+                    tb += red[(k * L.lanes_per_pix + L.cg) * 2 * V + V + r];
+                }
+                part[(prow * C + c + r) * 2] = ta;
+                part[(prow * C + c + r) * 2 + 1] = tb;
+            }
+        }
+    }
+}
+
+// grid of the up2 kernels: column slabs x row slabs x samples; reductions keep samples * gx * gy <= BN_MAX_PARTS partial rows
+inline dim3 up2_grid(int n, int h, int w, int c, int v, bool reduction) {
+    const int groups = c / v, lanes = groups < 256 ? groups : 256, pix_par = 256 / lanes;
+    int gx = ((2 * w + 2) / 4 + 1 + pix_par - 1) / pix_par;             // column groups {0}, {1..4}, {5..8}, ...
+    if (gx < 1) gx = 1;
+    int gy = 2 * h;
+    if (reduction) {
+        int budget = BN_MAX_PARTS / n;
+        if (budget < 1) budget = 1;
+        if (gx > budget) gx = budget;
+        gy = budget / gx;
+        if (gy > 2 * h) gy = 2 * h;
+        if (gy < 1) gy = 1;
+    }
+    return dim3((unsigned)gx, (unsigned)gy, (unsigned)n);
+}
+
 inline int ew_grid(long items) { long b = (items + 255) / 256; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); }
 
 // elementwise passes: blocks per sample so that a thread walks ~iters pixels (SP_TUNE_BN_ITERS)
@@ -454,12 +609,77 @@ extern "C" int sp_bn_apply_upsample2(const void* x, void* y, int32_t n, int32_t 
     Affine aff{gamma, beta, emb, cls};
     const int v = (dtype == SP_BF16 && c % 8 == 0) ? 8 : 4;
     const int groups = c / v, lanes = groups < 256 ? groups : 256, pix_par = 256 / lanes;
-    int bx = (2 * w_ + pix_par * 2 - 1) / (pix_par * 2);            // two output pixels per thread
+    int bx = ((2 * w_ + 2) / 4 + 1 + pix_par - 1) / pix_par;        // a thread: output columns 4q - 3 ... 4q
     if (bx < 1) bx = 1;
     const dim3 g(bx, (long)n * 2 * h < 65535 ? n * 2 * h : 65535);
     if (dtype == SP_F32) hipLaunchKernelGGL((bn_apply_upsample2_kernel<float, 4>), g, dim3(256), 0, s, (const float*)x, (float*)y, n, h, w_, c, mean, invstd, aff, act);
     else if (v == 8) hipLaunchKernelGGL((bn_apply_upsample2_kernel<bf16, 8>), g, dim3(256), 0, s, (const bf16*)x, (bf16*)y, n, h, w_, c, mean, invstd, aff, act);
     else hipLaunchKernelGGL((bn_apply_upsample2_kernel<bf16, 4>), g, dim3(256), 0, s, (const bf16*)x, (bf16*)y, n, h, w_, c, mean, invstd, aff, act);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_bn_stats_up2(const void* x, int32_t n, int32_t h, int32_t w_, int32_t c, float* partials, float eps, float momentum,
+                               float* running_mean, float* running_var, float* mean_out, float* invstd_out, int32_t dtype,
+                               sp_stream_t stream) {
+    SP_CHECK_ARG(x && partials && mean_out && invstd_out && c % 4 == 0 && n > 0 && n <= BN_MAX_PARTS && h > 0 && w_ > 0, "sp_bn_stats_up2: bad args");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int v = (dtype == SP_BF16 && c % 8 == 0) ? 8 : 4;
+    SP_CHECK_ARG(c / v <= 256, "sp_bn_stats_up2: at most %d channels", 256 * v);
+    const dim3 g = up2_grid(n, h, w_, c, v, true);
+    Affine none{nullptr, nullptr, nullptr, nullptr};
+    if (dtype == SP_F32) hipLaunchKernelGGL((bn_up2_kernel<float, 4, UP2_STATS>), g, dim3(256), 0, s, (const float*)x, h, w_, c, (const float*)nullptr, (float*)nullptr, nullptr, nullptr, none, 0, nullptr, nullptr, partials);
+    else if (v == 8) hipLaunchKernelGGL((bn_up2_kernel<bf16, 8, UP2_STATS>), g, dim3(256), 0, s, (const bf16*)x, h, w_, c, (const bf16*)nullptr, (bf16*)nullptr, nullptr, nullptr, none, 0, nullptr, nullptr, partials);
+    else hipLaunchKernelGGL((bn_up2_kernel<bf16, 4, UP2_STATS>), g, dim3(256), 0, s, (const bf16*)x, h, w_, c, (const bf16*)nullptr, (bf16*)nullptr, nullptr, nullptr, none, 0, nullptr, nullptr, partials);
+    SP_LAUNCH_CHECK();
+    const long pixels = (long)n * 4 * h * w_;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(sp_div_up(c, FIN_CL)), dim3(256), 0, s, partials, (int)(g.x * g.y * g.z), pixels, c, eps, momentum,
+                       running_mean, running_var, 1, mean_out, invstd_out);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_bn_apply_up2(const void* x, void* y, int32_t n, int32_t h, int32_t w_, int32_t c, const float* mean, const float* invstd,
+                               const float* gamma, const float* beta, const float* emb, const int64_t* cls, int32_t act, int32_t dtype,
+                               sp_stream_t stream) {
+    SP_CHECK_ARG(x && y && mean && invstd && c % 4 == 0 && n > 0 && n <= 65535, "sp_bn_apply_up2: bad args");
+    SP_CHECK_ARG(!emb || cls, "sp_bn_apply_up2: conditional mode needs class indices");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int v = (dtype == SP_BF16 && c % 8 == 0) ? 8 : 4;
+    SP_CHECK_ARG(c / v <= 256, "sp_bn_apply_up2: at most %d channels", 256 * v);
+    Affine aff{gamma, beta, emb, cls};
+    const dim3 g = up2_grid(n, h, w_, c, v, false);
+    if (dtype == SP_F32) hipLaunchKernelGGL((bn_up2_kernel<float, 4, UP2_APPLY>), g, dim3(256), 0, s, (const float*)x, h, w_, c, (const float*)nullptr, (float*)y, mean, invstd, aff, act, nullptr, nullptr, nullptr);
+    else if (v == 8) hipLaunchKernelGGL((bn_up2_kernel<bf16, 8, UP2_APPLY>), g, dim3(256), 0, s, (const bf16*)x, h, w_, c, (const bf16*)nullptr, (bf16*)y, mean, invstd, aff, act, nullptr, nullptr, nullptr);
+    else hipLaunchKernelGGL((bn_up2_kernel<bf16, 4, UP2_APPLY>), g, dim3(256), 0, s, (const bf16*)x, h, w_, c, (const bf16*)nullptr, (bf16*)y, mean, invstd, aff, act, nullptr, nullptr, nullptr);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_bn_backward_up2(const void* dy, const void* x, void* du, int32_t n, int32_t h, int32_t w_, int32_t c, const float* mean,
+                                  const float* invstd, const float* gamma, const float* beta, const float* emb, const int64_t* cls,
+                                  int32_t act, float* partials, float* c_tmp, float* dgamma, float* dbeta, float* demb,
+                                  int32_t num_classes, int32_t dtype, sp_stream_t stream) {
+    SP_CHECK_ARG(dy && x && du && mean && invstd && partials && c_tmp && c % 4 == 0 && n > 0 && n <= BN_MAX_PARTS, "sp_bn_backward_up2: bad args");
+    SP_CHECK_ARG(!emb || (cls && (!demb || num_classes > 0)), "sp_bn_backward_up2: conditional mode needs class indices");
+    SP_CHECK_ARG(!demb || n <= BN_EMB_MAXN, "sp_bn_backward_up2: the conditional backward supports batches up to %d", BN_EMB_MAXN);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int v = (dtype == SP_BF16 && c % 8 == 0) ? 8 : 4;
+    SP_CHECK_ARG(c / v <= 256, "sp_bn_backward_up2: at most %d channels", 256 * v);
+    Affine aff{gamma, beta, emb, cls};
+    const dim3 rg = up2_grid(n, h, w_, c, v, true);
+    if (dtype == SP_F32) hipLaunchKernelGGL((bn_up2_kernel<float, 4, UP2_BWD_REDUCE>), rg, dim3(256), 0, s, (const float*)x, h, w_, c, (const float*)dy, (float*)nullptr, mean, invstd, aff, act, nullptr, nullptr, partials);
+    else if (v == 8) hipLaunchKernelGGL((bn_up2_kernel<bf16, 8, UP2_BWD_REDUCE>), rg, dim3(256), 0, s, (const bf16*)x, h, w_, c, (const bf16*)dy, (bf16*)nullptr, mean, invstd, aff, act, nullptr, nullptr, partials);
+    else hipLaunchKernelGGL((bn_up2_kernel<bf16, 4, UP2_BWD_REDUCE>), rg, dim3(256), 0, s, (const bf16*)x, h, w_, c, (const bf16*)dy, (bf16*)nullptr, mean, invstd, aff, act, nullptr, nullptr, partials);
+    SP_LAUNCH_CHECK();
+    const long pixels = (long)n * 4 * h * w_;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sp_div_up(c, FIN_CL)), dim3(256), 0, s, partials, (int)(rg.x * rg.y), n, c, pixels, aff, c_tmp, c_tmp + c,
+                       dgamma, dbeta, demb, num_classes);
+    SP_LAUNCH_CHECK();
+    const dim3 g = up2_grid(n, h, w_, c, v, false);
+    if (dtype == SP_F32) hipLaunchKernelGGL((bn_up2_kernel<float, 4, UP2_BWD_APPLY>), g, dim3(256), 0, s, (const float*)x, h, w_, c, (const float*)dy, (float*)du, mean, invstd, aff, act, c_tmp, c_tmp + c, nullptr);
+    else if (v == 8) hipLaunchKernelGGL((bn_up2_kernel<bf16, 8, UP2_BWD_APPLY>), g, dim3(256), 0, s, (const bf16*)x, h, w_, c, (const bf16*)dy, (bf16*)du, mean, invstd, aff, act, c_tmp, c_tmp + c, nullptr);
+    else hipLaunchKernelGGL((bn_up2_kernel<bf16, 4, UP2_BWD_APPLY>), g, dim3(256), 0, s, (const bf16*)x, h, w_, c, (const bf16*)dy, (bf16*)du, mean, invstd, aff, act, c_tmp, c_tmp + c, nullptr);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }

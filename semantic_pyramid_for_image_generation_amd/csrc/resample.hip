@@ -242,21 +242,32 @@ __global__ __launch_bounds__(256) void upsample2_fwd_kernel(const T* __restrict_
         const T* r0 = x + ((long)n * H + h0) * W * C + c;
         const T* r1 = x + ((long)n * H + h1) * W * C + c;
         T* yr = y + ((long)n * OH + oh) * OW * C + c;
-#pragma unroll 2
-        for (int ow = blockIdx.x * pix_par + pl; ow < OW; ow += gridDim.x * pix_par) {
-            const float fw = sw * ow;
-            const int w0 = (int)fw;
-            const int w1 = w0 + (w0 < W - 1 ? 1 : 0);
-            const float lw = fw - w0;
-            float v00[V], v01[V], v10[V], v11[V], o[V];
-            VecIO<T, V>::ld(r0 + (long)w0 * C, v00);
-            VecIO<T, V>::ld(r0 + (long)w1 * C, v01);
-            VecIO<T, V>::ld(r1 + (long)w0 * C, v10);
-            VecIO<T, V>::ld(r1 + (long)w1 * C, v11);
+        // output columns 2k + 1 and 2k + 2 both interpolate between source columns k and k + 1 (align_corners: column ow sits at
+        // ow (W - 1) / (2W - 1)): a thread takes the four outputs 4q - 3 ... 4q from the THREE source columns 2q - 2, 2q - 1, 2q with a
+        // fixed pattern - 6 loads per 4 vectors instead of 16, no index arithmetic per output (round 4; rows first, then columns)
+        for (int q = blockIdx.x * pix_par + pl; 4 * q - 3 < OW; q += gridDim.x * pix_par) {
+            float t[3][V];
 #pragma unroll
-            for (int r = 0; r < V; ++r)
-                o[r] = (1.f - lh) * ((1.f - lw) * v00[r] + lw * v01[r]) + lh * ((1.f - lw) * v10[r] + lw * v11[r]);
-            VecIO<T, V>::st(yr + (long)ow * C, o);
+            for (int k = 0; k < 3; ++k) {
+                int col = 2 * q - 2 + k;
+                col = col < 0 ? 0 : (col < W ? col : W - 1);
+                float s0[V], s1[V];
+                VecIO<T, V>::ld(r0 + (long)col * C, s0);
+                VecIO<T, V>::ld(r1 + (long)col * C, s1);
+#pragma unroll
+                for (int r = 0; r < V; ++r) t[k][r] = (1.f - lh) * s0[r] + lh * s1[r];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ow = 4 * q - 3 + j;
+                if (ow < 0 || ow >= OW) continue;
+                const int w0 = 2 * q - 2 + (j >> 1);                           // = floor(ow (W - 1) / (2W - 1)) for ow >= 1
+                const float lw = ow == 0 ? 0.f : sw * ow - (float)w0;
+                float o[V];
+#pragma unroll
+                for (int r = 0; r < V; ++r) o[r] = (1.f - lw) * t[j >> 1][r] + lw * t[(j >> 1) + 1][r];
+                VecIO<T, V>::st(yr + (long)ow * C, o);
+            }
         }
     }
     }
@@ -447,7 +458,7 @@ extern "C" int sp_upsample2_fwd(const void* x, void* y, int32_t n, int32_t h, in
     // bf16 tensors with C % 8 == 0 move 16 bytes per lane, everything else 4 elements
     const int v = (dtype == SP_BF16 && c % 8 == 0) ? 8 : 4;
     const int groups = c / v, lanes = groups < 256 ? groups : 256, pix_par = 256 / lanes;
-    int bx = (2 * w_ + pix_par * 2 - 1) / (pix_par * 2);            // two output pixels per thread
+    int bx = ((2 * w_ + 2) / 4 + 1 + pix_par - 1) / pix_par;        // a thread: output columns 4q - 3 ... 4q
     if (bx < 1) bx = 1;
     const dim3 g(bx, (long)n * 2 * h < 65535 ? n * 2 * h : 65535);
     if (dtype == SP_F32) hipLaunchKernelGGL((upsample2_fwd_kernel<float, 4>), g, dim3(256), 0, s, (const float*)x, (float*)y, n, h, w_, c);

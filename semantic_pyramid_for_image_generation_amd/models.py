@@ -110,6 +110,9 @@ _FUSE_ACT_POOL = CFG.fuse_act_pool
 # SLOWER than the two kernels (897 vs 932 img/s: every source pixel is normalised by four output pixels and the class-gathered
 # affine is re-read per output vector), so it is off by default; the operator stays for A/B runs.
 _FUSE_BN_UPSAMPLE = CFG.fuse_bn_upsample
+# The generator's final block (models.py:52-54): UpsamplingBilinear2d -> BatchNorm2d -> LeakyReLU at 256 x 256 computed from the
+# 128 x 128 tensor, whose expansion is never written (6 instead of 17 low-resolution tensor volumes through HBM per forward).
+_FUSE_UPSAMPLE_BN = CFG.fuse_upsample_bn
 # The generator's masked-feature mappings on a side stream (Generator._map_features_ahead; a parallel branch of the captured graph):
 # built in round 4 and measured SLOWER - 1 139 vs 1 159 img/s, same box, alternating runs: the convolution kernels are persistent
 # (one block per CU walks the work items), so a second kernel on some CUs delays those blocks and with them the whole launch.
@@ -411,8 +414,13 @@ class Generator(nn.Module):
                     depth -= 1
             fb = self.final_block
             bn = fb[1]
-            x = ops.batch_norm(ops.upsample2(x), bn.weight, bn.bias, None, None, bn.running_mean, bn.running_var, bn.momentum,
-                               bn.eps, self.training, ACT_LRELU)
+            if _FUSE_UPSAMPLE_BN:
+                # UpsamplingBilinear2d -> BatchNorm2d -> LeakyReLU on the expansion of x without writing it (sp_bn_*_up2)
+                x = ops.batch_norm(x, bn.weight, bn.bias, None, None, bn.running_mean, bn.running_var, bn.momentum, bn.eps, self.training,
+                                   ACT_LRELU, "before")
+            else:
+                x = ops.batch_norm(ops.upsample2(x), bn.weight, bn.bias, None, None, bn.running_mean, bn.running_var, bn.momentum,
+                                   bn.eps, self.training, ACT_LRELU)
             x = fb[3](x, ACT_LRELU)
             return fb[5](x, ACT_TANH)
         finally:

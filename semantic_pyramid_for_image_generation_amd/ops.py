@@ -921,12 +921,27 @@ class _BatchNormFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, emb, cls, running_mean, running_var, momentum, eps, training, act, upsample=False):
+        """upsample: False; True = CBN -> act -> bilinear x2 in one pass (sp_bn_apply_upsample2); "before" = the normalised tensor
+        is the bilinear x2 expansion of x, never materialised (sp_bn_*_up2: the generator's final block)."""
         require_gpu(x)
         n, h, w, c = dims(x)
         dev = x.device
         sums = torch.empty(1024 * 2 * c, dtype=torch.float32, device=dev)        # per-block partial sums
         mean = torch.empty(c, dtype=torch.float32, device=dev)
         invstd = torch.empty(c, dtype=torch.float32, device=dev)
+        if upsample == "before":
+            if training:
+                L.call("sp_bn_stats_up2", ptr(x), n, h, w, c, ptr(sums), eps, momentum, ptr(running_mean), ptr(running_var), ptr(mean),
+                       ptr(invstd), sp_dtype(x.dtype), stream())
+            else:
+                L.call("sp_bn_stats", ptr(x), n, 4 * h * w, c, ptr(sums), eps, momentum, ptr(running_mean), ptr(running_var), 0, ptr(mean),
+                       ptr(invstd), sp_dtype(x.dtype), stream())          # eval: from the running statistics, x is not read
+            y = nhwc_empty(n, c, 2 * h, 2 * w, x.dtype, dev)
+            L.call("sp_bn_apply_up2", ptr(x), ptr(y), n, h, w, c, ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(emb), ptr(cls), act,
+                   sp_dtype(x.dtype), stream())
+            ctx.act, ctx.training, ctx.upsample = act, training, upsample
+            ctx.save_for_backward(x, gamma, beta, emb, cls, mean, invstd)
+            return y
         L.call("sp_bn_stats", ptr(x), n, h * w, c, ptr(sums), eps, momentum, ptr(running_mean), ptr(running_var),
                1 if training else 0, ptr(mean), ptr(invstd), sp_dtype(x.dtype), stream())
         if upsample:
@@ -950,6 +965,23 @@ class _BatchNormFn(torch.autograd.Function):
         n, h, w, c = dims(x)
         dev, dt = x.device, x.dtype
         dy = as_nhwc(dy, dt)
+        if ctx.upsample == "before":
+            du = nhwc_empty(n, c, 2 * h, 2 * w, dt, dev)
+            red = torch.empty(1024 * 2 * c, dtype=torch.float32, device=dev)
+            ctmp = torch.empty(2 * c, dtype=torch.float32, device=dev)
+            dgamma = dbeta = demb = None
+            classes = 0
+            if emb is not None:
+                demb = torch.empty_like(emb)
+                classes = emb.shape[0]
+            else:
+                dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+                dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+            L.call("sp_bn_backward_up2", ptr(dy), ptr(x), ptr(du), n, h, w, c, ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(emb),
+                   ptr(cls), ctx.act, ptr(red), ptr(ctmp), ptr(dgamma), ptr(dbeta), ptr(demb), classes, sp_dtype(dt), stream())
+            dx = nhwc_empty(n, c, h, w, dt, dev)
+            L.call("sp_upsample2_bwd", ptr(du), ptr(dx), n, h, w, c, sp_dtype(dt), stream())
+            return dx, dgamma, dbeta, demb, None, None, None, None, None, None, None, None
         if ctx.upsample:
             dlow = nhwc_empty(n, c, h, w, dt, dev)
             L.call("sp_upsample2_bwd", ptr(dy), ptr(dlow), n, h, w, c, sp_dtype(dt), stream())

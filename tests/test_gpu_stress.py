@@ -286,3 +286,61 @@ def test_pooling_and_attention_random_shapes(dtype, tol):
             if e > (tol if dtype == torch.float32 else 4e-2):
                 fails.append(("attention", rep, b, d, dv, hq, e))
     assert not fails, fails
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-4), (torch.bfloat16, 3e-2)])
+def test_batch_norm_of_the_bilinear_expansion_random_shapes(dtype, tol):
+    """The generator's final block (models.py:52-54): UpsamplingBilinear2d -> BatchNorm2d -> LeakyReLU computed from the
+    low-resolution tensor (sp_bn_*_up2, the expansion is never written) - against torch autograd, and against the library's own two
+    separate passes, which it must reproduce almost exactly (same interpolation, same rounding of the expansion)."""
+    _seed(9)
+    ops.set_compute_dtype(dtype)
+    fails = []
+    for it in range(14):
+        c = random.choice([4, 8, 16, 24, 64, 72, 128, 256])
+        n = random.randint(1, 5)
+        h, w = random.choice([1, 2, 3, 4, 8, 16, 31, 32, 64]), random.choice([1, 2, 4, 5, 8, 16, 32, 33, 64])
+        if n * h * w < 2:
+            continue
+        act, cond = random.choice([0, 1]), random.random() < 0.3
+        x0 = torch.randn(n, c, h, w, device='cuda').to(dtype).float()
+        gy = torch.randn(n, c, 2 * h, 2 * w, device='cuda').to(dtype).float()
+        emb = torch.randn(7, 2 * c, device='cuda') if cond else None
+        cls = torch.randint(0, 7, (n,), device='cuda') if cond else None
+        gamma = None if cond else torch.randn(c, device='cuda')
+        beta = None if cond else torch.randn(c, device='cuda')
+        xr = x0.clone().requires_grad_(True)
+        er = emb.clone().requires_grad_(True) if cond else None
+        gr = gamma.clone().requires_grad_(True) if not cond else None
+        br = beta.clone().requires_grad_(True) if not cond else None
+        u = F.interpolate(xr, scale_factor=2, mode='bilinear', align_corners=True)
+        mean, var = u.mean((0, 2, 3), keepdim=True), u.var((0, 2, 3), unbiased=False, keepdim=True)
+        uh = (u - mean) / torch.sqrt(var + 1e-5)
+        sc, bi = (er[cls][:, :c, None, None], er[cls][:, c:, None, None]) if cond else (gr[None, :, None, None], br[None, :, None, None])
+        yr = sc * uh + bi
+        if act:
+            yr = F.leaky_relu(yr, 0.2)
+        yr.backward(gy)
+        outs = []
+        for mode in ("before", "separate"):
+            xd = ops.as_nhwc(x0, dtype).requires_grad_(True)
+            ed = emb.clone().requires_grad_(True) if cond else None
+            gd = gamma.clone().requires_grad_(True) if not cond else None
+            bd = beta.clone().requires_grad_(True) if not cond else None
+            rm, rv = torch.zeros(c, device='cuda'), torch.ones(c, device='cuda')
+            if mode == "before":
+                y = ops.batch_norm(xd, gd, bd, ed, cls, rm, rv, 0.1, 1e-5, True, act, "before")
+            else:
+                y = ops.batch_norm(ops.upsample2(xd), gd, bd, ed, cls, rm, rv, 0.1, 1e-5, True, act)
+            y.backward(ops.as_nhwc(gy, dtype))
+            pg = [ed.grad] if cond else [gd.grad, bd.grad]
+            outs.append((y.detach().float(), xd.grad.float(), pg, rm, rv))
+        y, dx, pg, rm, rv = outs[0]
+        errs = [_rel(y, yr), _rel(dx, xr.grad)] + ([_rel(pg[0], er.grad)] if cond else [_rel(pg[0], gr.grad), _rel(pg[1], br.grad)])
+        if max(errs) > tol * (4 if n * h * w < (8 if dtype == torch.float32 else 64) else 1):      # few samples: 16-bit rounding of u weighs in
+            fails.append(("vs torch", n, c, h, w, act, cond, errs))
+        y2, dx2, pg2, rm2, rv2 = outs[1]
+        same = [_rel(y, y2), _rel(dx, dx2), _rel(rm, rm2 + 1e-12), _rel(rv, rv2)] + [_rel(a, b) for a, b in zip(pg, pg2)]
+        if max(same) > (1e-5 if dtype == torch.float32 else 2e-2):
+            fails.append(("vs separate passes", n, c, h, w, act, cond, same))
+    assert not fails, fails
