@@ -703,11 +703,13 @@ class _VGGPyramidFn(torch.autograd.Function):
             g = ops.nhwc_empty(n, 512, h, w, dtype, dev)
             Lb.call("sp_adaptive_avgpool_bwd", ops.ptr(dp7), None, ops.ptr(g), n, h, w, 512, 7, 7, ACT_NONE, sd, ops.stream())
         tap = 4
+        folded = False              # the tap gradient of the coming pool step already rode in the dgrad launch that produced g (res1)
         for step in reversed(ctx.trace):
             if step[0] == "pool":
                 xin = acts[step[1]]
                 _, c, h, w = xin.shape
-                gt = dfeats[tap]
+                gt = dfeats[tap] if not folded else None
+                folded = False
                 tap -= 1
                 if gt is not None:
                     gt = ops.as_nhwc(gt, dtype)
@@ -729,7 +731,13 @@ class _VGGPyramidFn(torch.autograd.Function):
                 # the producer of this conv's input is a ReLU (another conv) unless it is a pool output (already masked
                 # by the pool backward) or the image: fold that ReLU's derivative in via mask_src = the input itself
                 producer_is_conv = (not first) and ctx.trace[idx - 1][0] == "conv"
-                ops.conv_launch(g, pk["dgrad"].data_ptr(), None, dx, None, None, xin if producer_is_conv else None, 0.0, n, h, w,
+                # the input of this convolution is a pyramid tap (a pool output): the tap's own gradient (reconstruction loss) joins the
+                # chain in this launch's epilogue (res1) instead of a separate elementwise addition
+                res1 = None
+                if (not first) and ctx.trace[idx - 1][0] == "pool" and dfeats[tap] is not None and pk["cin"] == cin_p:
+                    res1 = ops.as_nhwc(dfeats[tap], dtype)
+                    folded = True
+                ops.conv_launch(g, pk["dgrad"].data_ptr(), None, dx, res1, None, xin if producer_is_conv else None, 0.0, n, h, w,
                                 g.shape[1], pk["cin"], cin_p, 3, ACT_NONE, dtype, family="dgrad")
                 g = dx
         if g is None:
