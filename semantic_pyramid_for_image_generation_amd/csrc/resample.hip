@@ -273,10 +273,13 @@ __global__ __launch_bounds__(256) void upsample2_fwd_kernel(const T* __restrict_
     }
 }
 
-// dx[h,w] = sum over output pixels whose taps include (h,w); weights recomputed exactly as in forward.
-// grid (column slabs, N * H): a block owns (part of) one INPUT row - its candidate output rows and their weights are
-// block-uniform, a thread keeps one channel group and walks columns (same summation order as the flat-index form it replaces:
-// output rows ascending, output columns ascending)
+// dx[h,w] = sum over the output pixels whose taps include (h,w), with the forward's weights.  With align_corners output row o >= 1
+// interpolates between input rows (o - 1) / 2 and (o - 1) / 2 + 1 (row 0 is input row 0), so input row h hears from exactly the
+// four output rows 2h - 1 ... 2h + 2 - likewise for columns.  grid (column slabs, N * H): a block owns (part of) one INPUT row,
+// whose four row weights are block-uniform; a thread keeps one channel group and produces TWO adjacent input columns from the six
+// output columns 2k - 1 ... 2k + 4 (column sums over the four rows first: 24 loads per two results).  Round 4: the first form walked
+// a bounding range of candidate rows / columns per pixel and tested each one's taps (~49 candidates with floor / ceil / divisions for
+// 16 hits: 2.3 TB/s on the 256 x 256 layer).
 template <typename T, int V>
 __global__ __launch_bounds__(256) void upsample2_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W, int C) {
     const int OH = 2 * H, OW = 2 * W;
@@ -285,46 +288,61 @@ __global__ __launch_bounds__(256) void upsample2_bwd_kernel(const T* __restrict_
     const int ngroups = C / V;
     const int lanes_per_pix = ngroups < 256 ? ngroups : 256, pix_par = 256 / lanes_per_pix;
     const int cg = threadIdx.x % lanes_per_pix, pl = threadIdx.x / lanes_per_pix;
+    // weight of output index o (extent O = 2 I, scale s) on input index i
+    auto tap_weight = [](int o, int O, int I, float s, int i) {
+        if (o < 0 || o >= O) return 0.f;
+        const int i0 = o == 0 ? 0 : (o - 1) >> 1;
+        const float l = o == 0 ? 0.f : s * o - (float)i0;
+        const int i1 = i0 + 1 < I ? i0 + 1 : I - 1;
+        return (i0 == i ? 1.f - l : 0.f) + (i1 == i ? l : 0.f);
+    };
     for (int row = blockIdx.y; row < N * H; row += gridDim.y) {
-        const int n = row / H, oh = row - n * H;                    // (oh, ow) = input pixel
-        // candidate output rows: src in (oh-1, oh+1)  ->  o in ((oh-1)/sh, (oh+1)/sh)
-        const int olo = sh > 0.f ? max(0, (int)floorf((oh - 1) / sh) - 1) : 0;
-        const int ohi = sh > 0.f ? min(OH - 1, (int)ceilf((oh + 1) / sh) + 1) : OH - 1;
+        const int n = row / H, h = row - n * H;
+        float wh[4];
+        long roff[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = 2 * h - 1 + i;
+            wh[i] = tap_weight(o, OH, H, sh, h);
+            roff[i] = (long)(o < 0 ? 0 : (o < OH ? o : OH - 1)) * OW * C;
+        }
         for (int cbase = 0; cbase < ngroups; cbase += lanes_per_pix) {
             const int c = (cbase + cg) * V;
             if (c >= C || pl >= pix_par) continue;
             const T* dyn = dy + (long)n * OH * OW * C + c;
-            T* dxr = dx + ((long)n * H + oh) * W * C + c;
-            for (int ow = blockIdx.x * pix_par + pl; ow < W; ow += gridDim.x * pix_par) {
-                float a[V], t[V];
+            T* dxr = dx + ((long)n * H + h) * W * C + c;
+            for (int kp = blockIdx.x * pix_par + pl; 2 * kp < W; kp += gridDim.x * pix_par) {
+                const int k = 2 * kp;
+                float vs[6][V];
 #pragma unroll
-                for (int r = 0; r < V; ++r) a[r] = 0.f;
-                const int plo = sw > 0.f ? max(0, (int)floorf((ow - 1) / sw) - 1) : 0;
-                const int phi = sw > 0.f ? min(OW - 1, (int)ceilf((ow + 1) / sw) + 1) : OW - 1;
-                for (int o = olo; o <= ohi; ++o) {
-                    const float fh = sh * o;
-                    const int h0 = (int)fh;
-                    const int h1 = h0 + (h0 < H - 1 ? 1 : 0);
-                    const float lh = fh - h0;
-                    float wh = 0.f;
-                    if (h0 == oh) wh += 1.f - lh;
-                    if (h1 == oh) wh += lh;
-                    if (wh == 0.f) continue;
-                    for (int p = plo; p <= phi; ++p) {
-                        const float fw = sw * p;
-                        const int w0 = (int)fw;
-                        const int w1 = w0 + (w0 < W - 1 ? 1 : 0);
-                        const float lw = fw - w0;
-                        float ww = 0.f;
-                        if (w0 == ow) ww += 1.f - lw;
-                        if (w1 == ow) ww += lw;
-                        if (ww == 0.f) continue;
-                        VecIO<T, V>::ld(dyn + ((long)o * OW + p) * C, t);
+                for (int j = 0; j < 6; ++j) {
+                    const int pcol = 2 * k - 1 + j;
+                    const long coff = (long)(pcol < 0 ? 0 : (pcol < OW ? pcol : OW - 1)) * C;
 #pragma unroll
-                        for (int r = 0; r < V; ++r) a[r] += wh * ww * t[r];
+                    for (int r = 0; r < V; ++r) vs[j][r] = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float t[V];
+                        VecIO<T, V>::ld(dyn + roff[i] + coff, t);
+#pragma unroll
+                        for (int r = 0; r < V; ++r) vs[j][r] += wh[i] * t[r];
                     }
                 }
-                VecIO<T, V>::st(dxr + (long)ow * C, a);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int kk = k + m;
+                    if (kk >= W) break;
+                    float a[V];
+#pragma unroll
+                    for (int r = 0; r < V; ++r) a[r] = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float ww = tap_weight(2 * kk - 1 + j, OW, W, sw, kk);
+#pragma unroll
+                        for (int r = 0; r < V; ++r) a[r] += ww * vs[2 * m + j][r];
+                    }
+                    VecIO<T, V>::st(dxr + (long)kk * C, a);
+                }
             }
         }
     }
@@ -475,7 +493,7 @@ extern "C" int sp_upsample2_bwd(const void* dy, void* dx, int32_t n, int32_t h, 
     // bf16 tensors with C % 8 == 0 move 16 bytes per lane, everything else 4 elements
     const int v = (dtype == SP_BF16 && c % 8 == 0) ? 8 : 4;
     const int groups = c / v, lanes = groups < 256 ? groups : 256, pix_par = 256 / lanes;
-    int bx = (w_ + pix_par - 1) / pix_par;                            // one input pixel (up to 16 gradient vectors) per thread
+    int bx = ((w_ + 1) / 2 + pix_par - 1) / pix_par;                  // two adjacent input columns per thread
     if (bx < 1) bx = 1;
     const dim3 g(bx, (long)n * h < 65535 ? n * h : 65535);
     if (dtype == SP_F32) hipLaunchKernelGGL((upsample2_bwd_kernel<float, 4>), g, dim3(256), 0, s, (const float*)dy, (float*)dx, n, h, w_, c);
