@@ -141,6 +141,16 @@ typedef struct sp_conv_params {
     int32_t img_split;      /* images [0, img_split) use img_scale[0], the rest img_scale[1] */
     int32_t reserved_;
     int64_t split_pix_;     /* set by the library (first OUTPUT pixel index of the second group); callers leave it 0 */
+    /* Fused 1x1 tail (16-bit storage, 3x3, cout == 64, h % 16 == 0, w % 32 == 0, ldy % 8 == 0, no pooling; SP_ERR_UNSUPPORTED elsewhere):
+     *   tail_y[n,h,w,o] = tail_act( sum_c tail_w[o][c] * y[n,h,w,c] + tail_bias[o] ),  o < tail_cout <= 4
+     * computed in the epilogue from the (16-bit rounded) y of this launch - the generator's last two layers, conv3x3 -> LeakyReLU ->
+     * conv1x1 -> tanh (models.py:55-61), in one launch.  y may then be NULL (a forward pass that never looks at the 64-channel tensor
+     * again): the 168 MB tensor of the 256 x 256 layer is neither written nor read back.  tail_w: [tail_cout][64] in the storage type
+     * (the forward packing of the 1x1 layer), tail_y pitch tail_ld elements. */
+    const void* tail_w;
+    const float* tail_bias;
+    void* tail_y;
+    int32_t tail_cout, tail_act, tail_ld, reserved2_;
 } sp_conv_params;
 int sp_conv2d_igemm(const sp_conv_params* p, sp_stream_t stream);
 /* Bytes of fp32 scratch sp_conv2d_igemm wants in sp_conv_params.workspace to split the K loop of this shape over several

@@ -13,6 +13,7 @@ results beyond floating-point summation order.  The kernel library itself reads 
     fuse_act_pool         SP_FUSE_ACT_POOL       1        LeakyReLU + AvgPool of a discriminator block's input in one pass
     fuse_bn_upsample      SP_FUSE_BN_UPSAMPLE    0        CBN + LeakyReLU + bilinear x2 in one kernel (measured slower)
     fuse_upsample_bn      SP_FUSE_UPSAMPLE_BN    1        bilinear x2 -> BatchNorm -> LeakyReLU of the generator's final block without materialising the 256 x 256 expansion
+    fuse_tail             SP_FUSE_TAIL           1        no-grad generator forward: its last conv1x1 + tanh in the epilogue of the conv3x3 before it
     pool2_bwd_fused       SP_POOL2_BWD_FUSED     1        pooled gradients read directly by dgrad / weight gradient (no full-resolution tensor)
     graph_after           SP_GRAPH_AFTER         3        ModelWrapper.train(): capture HIP graphs after this many eager iterations (0 = never)
     d_pair                SP_D_PAIR              1        D(real) and D(fake) of the discriminator step as one two-group pass over 2B images (models.Discriminator.forward_pair)
@@ -46,6 +47,7 @@ class Config:
     f16_loss_scale: float = 65536.0
     side_features: bool = False
     fuse_upsample_bn: bool = True
+    fuse_tail: bool = True
 
     @classmethod
     def from_env(cls) -> "Config":
@@ -55,7 +57,7 @@ class Config:
                    pool2_bwd_fused=_flag("SP_POOL2_BWD_FUSED", True), graph_after=int(os.environ.get("SP_GRAPH_AFTER", "3")), vgg_fp8=int(os.environ.get("SP_VGG_FP8", "0")),
                    d_pair=_flag("SP_D_PAIR", True), f16_loss_scale=float(os.environ.get("SP_F16_LOSS_SCALE", "65536")),
                    side_features=_flag("SP_SIDE_FEATURES", False),
-                   fuse_upsample_bn=_flag("SP_FUSE_UPSAMPLE_BN", True))
+                   fuse_upsample_bn=_flag("SP_FUSE_UPSAMPLE_BN", True), fuse_tail=_flag("SP_FUSE_TAIL", True))
 
 
 CFG = Config.from_env()

@@ -1609,7 +1609,7 @@ extern "C" int sp_conv2d_workspace(int32_t n, int32_t h, int32_t w_, int32_t cin
 extern "C" int sp_conv2d_igemm(const sp_conv_params* pp, sp_stream_t stream) {
     SP_CHECK_ARG(pp != nullptr, "sp_conv2d_igemm: null params");
     const sp_conv_params& p = *pp;
-    SP_CHECK_ARG(p.x && p.w && (p.y || (p.dtype == SP_F8 && p.y8)), "sp_conv2d_igemm: null tensor pointer");
+    SP_CHECK_ARG(p.x && p.w && (p.y || (p.dtype == SP_F8 && p.y8) || (p.tail_w && p.tail_y)), "sp_conv2d_igemm: null tensor pointer");
     SP_CHECK_ARG(p.ksize == 1 || p.ksize == 3, "sp_conv2d_igemm: ksize %d unsupported (1 or 3)", p.ksize);
     SP_CHECK_ARG(p.n > 0 && p.h > 0 && p.w_ > 0 && p.cin_p > 0 && p.cout > 0, "sp_conv2d_igemm: bad dims");
     SP_CHECK_ARG(p.dtype == SP_F32 || p.dtype == SP_BF16 || p.dtype == SP_F8, "sp_conv2d_igemm: bad dtype %d", p.dtype);
@@ -1639,6 +1639,19 @@ extern "C" int sp_conv2d_igemm(const sp_conv_params* pp, sp_stream_t stream) {
                          p.mask_src == nullptr,
                      "sp_conv2d_igemm: pool2 needs a 3x3 layer with cout > 32, cout %% 16 == 0, h %% 8 == 0, w %% 32 == 0, ldy %% 8 == 0 and no mask_src");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (p.tail_w != nullptr) {
+        // fused 1x1 tail: the 64-channel FAST form of the ping-pong kernel only - no silent fall-back to a kernel that would ignore it
+        SP_CHECK_ARG(p.tail_y && p.tail_cout >= 1 && p.tail_cout <= 4 && p.tail_ld >= p.tail_cout && (p.tail_act == SP_ACT_NONE || p.tail_act == SP_ACT_TANH),
+                     "sp_conv2d_igemm: bad tail arguments");
+        const bool ok = p.dtype == SP_BF16 && p.ksize == 3 && p.cout == 64 && p.h % 16 == 0 && p.w_ % 32 == 0 && (p.ldy & 7) == 0 && !p.pool2 &&
+                        !p.in_up2 && p.act != SP_ACT_TANH && p.img_scale == nullptr && sp_tune(SP_TUNE_CONV_PP, 1) && sp_tune(SP_TUNE_CONV_TALL, 1) == 1 &&
+                        !(sp_tune(SP_TUNE_CONV_PP_PRIO, 1) & 16);
+        if (!ok || sp_conv_pp_launch(p, 16, s) != SP_OK) {
+            sp_set_error("sp_conv2d_igemm: the fused 1x1 tail needs 16-bit storage, a 3x3 layer with cout == 64, h %% 16 == 0, w %% 32 == 0, ldy %% 8 == 0, no pooling");
+            return SP_ERR_UNSUPPORTED;
+        }
+        return SP_OK;
+    }
     if (p.img_scale != nullptr) {
         SP_CHECK_ARG(p.img_split >= 0 && p.img_split <= p.n, "sp_conv2d_igemm: img_split %d outside [0, n]", p.img_split);
         sp_conv_params q = p;                              // first output pixel of the second group (pooled geometry with pool2)

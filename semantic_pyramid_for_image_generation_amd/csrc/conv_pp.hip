@@ -59,7 +59,8 @@ struct PPGeom {
     static constexpr bool F8 = sizeof(T) == 1;                        // SP_F8: e4m3 operands, per-channel dequantisation scales in LDS
     static constexpr int OFF_W = 2 * HALO_BUF, OFF_BIAS = OFF_W + NWS * W_BYTES, OFF_SCALE = OFF_BIAS + PP_BIAS_MAX * 4;
     static constexpr int OFF_DUMMY = OFF_SCALE + (F8 ? PP_BIAS_MAX * 4 : 0);
-    static constexpr int LDS = OFF_DUMMY + 1024;
+    static constexpr int OFF_TAIL = OFF_DUMMY + 1024;                 // fused 1x1 tail (sp_conv_params.tail_w): [4][64] weights + [4] bias, fp32
+    static constexpr int LDS = OFF_TAIL + (WCO == 1 && FW == 2 && !F8 ? 4 * 64 * 4 + 16 : 0);
 };
 
 // number of (halo row h', tap row dr') MFMA groups that precede group (h, dr) in the MFMA segment's order (h outer, dr inner)
@@ -108,6 +109,14 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
         float* bias_l = reinterpret_cast<float*>(smem + G::OFF_BIAS);
         const int nb = cotiles * CO_T < PP_BIAS_MAX ? cotiles * CO_T : PP_BIAS_MAX;
         for (int i = tid; i < nb; i += 512) bias_l[i] = (p.bias != nullptr && i < p.cout) ? p.bias[i] : 0.f;
+        if constexpr (FAST && WCO == 1 && FW == 2) {
+            if (p.tail_w != nullptr) {                       // fused 1x1 tail: weights [tail_cout][64] (16-bit, the 1x1 layer's forward packing) -> fp32
+                float* tail_l = reinterpret_cast<float*>(smem + G::OFF_TAIL);
+                const T* tw = reinterpret_cast<const T*>(p.tail_w);
+                for (int i = tid; i < 4 * 64; i += 512) tail_l[i] = (i >> 6) < p.tail_cout ? Elem<T>::ld(tw + i) : 0.f;
+                if (tid < 4) tail_l[4 * 64 + tid] = (p.tail_bias != nullptr && tid < p.tail_cout) ? p.tail_bias[tid] : 0.f;
+            }
+        }
         if constexpr (G::F8) {                               // dequantisation scale of (x, w[co]) per output channel
             float* scale_l = reinterpret_cast<float*>(smem + G::OFF_SCALE);
             const float sx = p.x_scale[0];
@@ -446,6 +455,46 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) acc[i][jj][r] = fmaxf(acc[i][jj][r], 0.f);
                     }
+                    if constexpr (WCO == 1 && FW == 2) {
+                        // fused 1x1 tail (the generator's last two layers, models.py:55-61: conv3x3 -> LeakyReLU -> conv1x1 -> tanh): the 64
+                        // channels of a pixel sit in the four lanes l, l + 16, l + 32, l + 48 - each takes the dot products of its 16
+                        // channels with the tail's rows (LDS copy), two butterfly steps add them up, lane group 0 stores the pixel's
+                        // tail_cout values.  The 16-bit rounding of the intermediate tensor is applied first: the separate 1x1 layer reads it
+                        // from memory in that precision.
+                        if (p.tail_w != nullptr) {
+                            const float* tail_l = reinterpret_cast<const float*>(smem + G::OFF_TAIL);
+                            const int cg16 = (lane >> 4) * 16;
+                            T* ty = reinterpret_cast<T*>(p.tail_y);
+                            for (int o = 0; o < p.tail_cout; ++o) {
+                                float wv[16];
+#pragma unroll
+                                for (int c4 = 0; c4 < 4; ++c4) {
+                                    const float4 t4 = *reinterpret_cast<const float4*>(tail_l + o * 64 + cg16 + c4 * 4);
+                                    wv[c4 * 4] = t4.x; wv[c4 * 4 + 1] = t4.y; wv[c4 * 4 + 2] = t4.z; wv[c4 * 4 + 3] = t4.w;
+                                }
+                                const float tb = tail_l[4 * 64 + o];
+#pragma unroll
+                                for (int jj = 0; jj < NFR; ++jj) {
+                                    float part = 0.f;
+#pragma unroll
+                                    for (int k = 0; k < 8; ++k) {
+                                        const uint32_t w2 = f32x2_to_bf16x2(acc[k >> 1][jj][2 * (k & 1)], acc[k >> 1][jj][2 * (k & 1) + 1]);
+                                        part = fmaf(h16_lo_to_f32(w2), wv[2 * k], part);
+                                        part = fmaf(h16_hi_to_f32(w2), wv[2 * k + 1], part);
+                                    }
+                                    part += __shfl_xor(part, 16, 64);
+                                    part += __shfl_xor(part, 32, 64);
+                                    if (lane < 16) {
+                                        float tv = part + tb;
+                                        if (p.tail_act == SP_ACT_TANH) tv = tanhf(tv);
+                                        const long tpix = pix0 + (long)(jj / FW) * W + (jj % FW) * 16;
+                                        Elem<T>::st(ty + tpix * p.tail_ld + o, tv);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    if (p.y != nullptr)
                     static_for<NFR>([&](auto jc) {
                         constexpr int j = decltype(jc)::value;
                         unsigned w8[8];
@@ -655,6 +704,7 @@ int sp_conv_pp_launch(const sp_conv_params& p, int th, hipStream_t s) {
     // bit 4 = the general epilogue everywhere
     const int prio = sp_tune(SP_TUNE_CONV_PP_PRIO, 1);
     const bool fast = !(prio & 16) && p.pool2 == 0 && (p.cout & 15) == 0 && (p.ldy & 7) == 0 && p.act != SP_ACT_TANH;
+    if (p.tail_w != nullptr && !(th == 16 && p.cout == 64 && fast)) return 1;      // the fused 1x1 tail lives in the 64-channel FAST form only
     if (th == 16 && p.cout <= 64)                          // 64 co x 16x32 px
         return fast ? launch_pp<bf16, 1, 1, false, true, true>(p, prio, s) : launch_pp<bf16, 1, 1>(p, prio, s);
     if (th != 8 || p.cout <= 64) return 1;

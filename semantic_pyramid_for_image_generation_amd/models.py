@@ -421,6 +421,8 @@ class Generator(nn.Module):
             else:
                 x = ops.batch_norm(ops.upsample2(x), bn.weight, bn.bias, None, None, bn.running_mean, bn.running_var, bn.momentum,
                                    bn.eps, self.training, ACT_LRELU)
+            if ops.conv_tail_ok(x, fb[3], fb[5]):
+                return ops.sn_conv2d_tail(x, fb[3], ACT_LRELU, fb[5], ACT_TANH)     # no-grad pass: the 1x1 + tanh ride in the 3x3's epilogue
             x = fb[3](x, ACT_LRELU)
             return fb[5](x, ACT_TANH)
         finally:

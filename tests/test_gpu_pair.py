@@ -111,3 +111,40 @@ def test_img_scale_every_route(dt, case):
                          scales.data_ptr(), split)
         err = float((y.float() - ref).abs().max() / ref.abs().max())
         assert err <= (3e-4 if dt == torch.float32 else 1e-2), (case, err)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_fused_1x1_tail_matches_the_two_launches(dt):
+    """sp_conv_params.tail_w: conv3x3 (64 -> 64) -> LeakyReLU -> conv1x1 (64 -> 3) -> tanh in one launch (the generator's last two
+    layers in a pass without autograd) against the two separate launches on the same packed weights - equal up to the summation
+    order of the 64-term dot product - and with the 64-channel output also requested."""
+    import ctypes
+    from semantic_pyramid_for_image_generation_amd import _lib as L
+    torch.manual_seed(5)
+    n, h, w = 3, 32, 64
+    x = ops.nhwc_empty(n, 64, h, w, dt, "cuda").normal_()
+    w3 = (torch.randn(64, 3, 3, 64, device="cuda") * 0.05).to(dt)
+    w1 = (torch.randn(3, 1, 1, 64, device="cuda") * 0.2).to(dt)
+    b3, b1 = torch.randn(64, device="cuda") * 0.1, torch.randn(3, device="cuda") * 0.1
+    y64 = ops.nhwc_empty(n, 64, h, w, dt, "cuda")
+    ops._conv_launch(x, w3.data_ptr(), b3, y64, None, None, None, 0.0, n, h, w, 64, 64, 64, 3, ops.ACT_LRELU, dt)
+    ref = ops.nhwc_empty(n, 3, h, w, dt, "cuda")
+    ops._conv_launch(y64, w1.data_ptr(), b1, ref, None, None, None, 0.0, n, h, w, 64, 3, 3, 1, ops.ACT_TANH, dt)
+    for keep in (False, True):
+        out = ops.nhwc_empty(n, 3, h, w, dt, "cuda").fill_(-7.0)
+        mid = ops.nhwc_empty(n, 64, h, w, dt, "cuda").fill_(-7.0) if keep else None
+        p = L.SpConvParams()
+        p.x, p.w, p.bias, p.y = x.data_ptr(), w3.data_ptr(), b3.data_ptr(), (mid.data_ptr() if keep else None)
+        p.n, p.h, p.w_, p.cin_p, p.cout, p.ldy, p.ksize, p.act, p.dtype = n, h, w, 64, 64, 64, 3, ops.ACT_LRELU, ops.sp_dtype(dt)
+        p.tail_w, p.tail_bias, p.tail_y, p.tail_cout, p.tail_act, p.tail_ld = w1.data_ptr(), b1.data_ptr(), out.data_ptr(), 3, ops.ACT_TANH, 3
+        for _ in range(2):
+            L.call("sp_conv2d_igemm", ctypes.byref(p), ops.stream())
+        torch.cuda.synchronize()
+        err = float((out.float() - ref.float()).abs().max())
+        assert err <= (1.6e-2 if dt == torch.bfloat16 else 2e-3), (keep, err)
+        if keep:
+            assert torch.equal(mid, y64)
+    # outside its shapes the tail is refused loudly (no silent launch of a kernel that ignores it)
+    p.cout = 128
+    with pytest.raises(L.SempyrError):
+        L.call("sp_conv2d_igemm", ctypes.byref(p), ops.stream())
