@@ -216,3 +216,32 @@ def test_reducer_is_identity_without_process_group():
     p.grad = torch.full((4,), 3.0)
     GradientReducer().reduce([p])
     assert torch.equal(p.grad, torch.full((4,), 3.0))
+
+
+def _agree_worker(rank, world, port, results):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import semantic_pyramid_for_image_generation_amd as sp
+        from semantic_pyramid_for_image_generation_amd.distributed import GradientReducer
+        G, D = sp.Generator(channels_factor=16), sp.Discriminator(channel_factor=16)
+        mw = sp.ModelWrapper(G, D, None, None, vgg16=sp.VGG16(), save_data_path=None, gradient_reducer=GradientReducer())
+        assert mw._reducer_active()
+        # one rank's capture failed: every rank must learn it (the eager and the replay path issue different collective sequences)
+        results[rank] = (mw._ranks_agree(rank != 1), mw._ranks_agree(True))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_agree_on_the_outcome_of_a_graph_capture():
+    """Round-3 ADVICE: ModelWrapper.train() decides capture / replay / eager fallback per process; under data parallelism a rank
+    that failed to capture must pull every rank back to eager launches (all-reduce(MIN) of the per-rank flag)."""
+    world = 2
+    port = _free_port()
+    with mp.Manager() as mgr:
+        results = mgr.dict()
+        mp.spawn(_agree_worker, args=(world, port, results), nprocs=world, join=True)
+        assert len(results) == world
+        for r in range(world):
+            assert results[r] == (False, True), (r, results[r])
