@@ -260,6 +260,11 @@ typedef struct sp_sn_bwd_layer {
 int sp_sn_backward_batched(const sp_sn_bwd_layer* table_dev, int32_t n_layers, int64_t max_elems, float* arena,
                            const float* scratch, float* grads, const float* accumulate_from, float* bias_grads,
                            float* dot_partials, sp_stream_t stream);
+/* The same with every gradient it writes (weights and biases) multiplied by grad_scale: the SP_F16 mode's static loss scale comes
+ * off where the (fp32) parameter gradients are formed, without a pass of its own over the buffer. */
+int sp_sn_backward_batched_scaled(const sp_sn_bwd_layer* table_dev, int32_t n_layers, int64_t max_elems, float* arena,
+                                  const float* scratch, float* grads, const float* accumulate_from, float* bias_grads,
+                                  float* dot_partials, float grad_scale, sp_stream_t stream);
 
 /* One-off packing of a frozen, non-normalised fp32 weight (the VGG-16 pyramid, models.py:176-181) into the
  * same two packings.  chw_c > 0: the input-feature index is permuted from NCHW-flatten (c*chw_hw + s) to

@@ -344,11 +344,11 @@ __global__ __launch_bounds__(256) void sn_bwd_dot_batched_kernel(const sp_sn_bwd
 
 __global__ __launch_bounds__(256) void sn_bwd_apply_batched_kernel(const sp_sn_bwd_layer* __restrict__ table, const float* __restrict__ arena,
                                                                    const float* __restrict__ scratch, float* grads, const float* prev,
-                                                                   float* bias_grads, const float* __restrict__ dot_partials) {
+                                                                   float* bias_grads, const float* __restrict__ dot_partials, float grad_scale) {
     const sp_sn_bwd_layer L = table[blockIdx.y];
     if (bias_grads != nullptr && blockIdx.x == 0) {            // bias gradients: plain sums, copied / added as they are
         for (int r = threadIdx.x; r < L.rows; r += 256) {
-            const float b = arena[L.db_off + r];
+            const float b = arena[L.db_off + r] * grad_scale;
             bias_grads[L.bias_off + r] = prev ? bias_grads[L.bias_off + r] + b : b;
         }
     }
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void sn_bwd_apply_batched_kernel(const sp_sn_b
             const int ci = c / L.taps, tap = c - ci * L.taps;
             src = ((long)r * L.taps + tap) * L.cin_p + ci;
         }
-        const float gv = (dwsn[src] - coef * usnap[r] * vsnap[c]) * inv_sigma;
+        const float gv = (dwsn[src] - coef * usnap[r] * vsnap[c]) * inv_sigma * grad_scale;      // (x 1.0f is exact: the plain entry's results are unchanged)
         grad[e] = acc ? acc[e] + gv : gv;
     }
 }
@@ -498,6 +498,12 @@ extern "C" int sp_sn_backward(const float* dwsn, const float* w_orig, const floa
 extern "C" int sp_sn_backward_batched(const sp_sn_bwd_layer* table_dev, int32_t n_layers, int64_t max_elems, float* arena,
                                       const float* scratch, float* grads, const float* accumulate_from, float* bias_grads,
                                       float* dot_partials, sp_stream_t stream) {
+    return sp_sn_backward_batched_scaled(table_dev, n_layers, max_elems, arena, scratch, grads, accumulate_from, bias_grads, dot_partials, 1.0f, stream);
+}
+
+extern "C" int sp_sn_backward_batched_scaled(const sp_sn_bwd_layer* table_dev, int32_t n_layers, int64_t max_elems, float* arena,
+                                             const float* scratch, float* grads, const float* accumulate_from, float* bias_grads,
+                                             float* dot_partials, float grad_scale, sp_stream_t stream) {
     SP_CHECK_ARG(table_dev && arena && scratch && grads && dot_partials && n_layers > 0 && max_elems > 0, "sp_sn_backward_batched: bad args");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int bx = (int)((max_elems + 1023) / 1024);
@@ -505,7 +511,7 @@ extern "C" int sp_sn_backward_batched(const sp_sn_bwd_layer* table_dev, int32_t 
     dim3 grid(bx, n_layers);
     hipLaunchKernelGGL(sn_bwd_dot_batched_kernel, grid, dim3(256), 0, s, table_dev, arena, dot_partials);
     hipLaunchKernelGGL(sn_bwd_apply_batched_kernel, grid, dim3(256), 0, s, table_dev, arena, scratch, grads, accumulate_from, bias_grads,
-                       dot_partials);
+                       dot_partials, grad_scale);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }

@@ -125,7 +125,9 @@ class ModelWrapper(object):
             bank.on_group_done = None
             bank.collect_extra()
             if bank.flat is not None:
-                ops.unscale_(bank.flat)                 # fp16 mode: the static loss scale comes off the (fp32) parameter gradients
+                # fp16 mode: the static loss scale has come off the spectral-normalised layers' gradients inside their batched
+                # backward; the tail of the buffer (gradients that arrived through autograd) loses it here (16-byte aligned offset)
+                ops.unscale_(bank.flat, bank.sn_floats)
         elif ops.loss_scale() != 1.0:
             raise ops.L.SempyrError("the fp16 storage mode needs the flat gradient buffers (config.CFG.direct_grads) for its loss scale")
 

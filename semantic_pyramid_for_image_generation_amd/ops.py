@@ -61,11 +61,13 @@ def loss_scale_seed(device) -> Optional[torch.Tensor]:
     return t
 
 
-def unscale_(flat: torch.Tensor) -> None:
-    """flat *= 1 / loss_scale(), in place, one launch of the library (no-op outside the fp16 mode)."""
+def unscale_(flat: torch.Tensor, start: int = 0) -> None:
+    """flat[start:] *= 1 / loss_scale(), in place, one launch of the library (no-op outside the fp16 mode).  The spectral-normalised
+    layers' gradients lose the scale inside the batched backward (sp_sn_backward_batched_scaled); this is for the tail of a bank's
+    buffer - the few parameters whose gradients arrive through autograd (ops.SpectralNormBank.collect_extra)."""
     s = loss_scale()
-    if s != 1.0:
-        L.call("sp_scale_f32", ptr(flat), flat.numel(), 1.0 / s, stream())
+    if s != 1.0 and flat.numel() > start:
+        L.call("sp_scale_f32", ctypes.c_void_p(flat.data_ptr() + 4 * start), flat.numel() - start, 1.0 / s, stream())
 
 
 def compute_dtype() -> torch.dtype:
@@ -258,8 +260,9 @@ class _SNBankFn(torch.autograd.Function):
             # parameters' .grad are views of it - autograd neither sums nor stores anything for these parameters
             bank.enter_backward(call.arena.device, g)
             prev = bank.flat if bank.group_count[g] > 0 else None
-            L.call("sp_sn_backward_batched", table, n, bank.max_elems, ptr(call.arena), ptr(call.scratch),
-                   ptr(bank.flat), ptr(prev), ptr(bank.flat), ptr(dots), stream())
+            # (fp16 mode: the loss scale comes off right here, where the fp32 parameter gradients are formed)
+            L.call("sp_sn_backward_batched_scaled", table, n, bank.max_elems, ptr(call.arena), ptr(call.scratch),
+                   ptr(bank.flat), ptr(prev), ptr(bank.flat), ptr(dots), 1.0 / loss_scale(), stream())
             bank.group_count[g] += 1
             for i in range(lo, hi):
                 m = bank.specs[i][0]
