@@ -24,7 +24,7 @@ import torch.nn as nn
 from . import misc, ops, profiling
 from .config import CFG
 from .lossfunction import DiversityLoss, LSGANDiscriminatorLoss, LSGANGeneratorLoss, SemanticReconstructionLoss
-from .models import VGG16, Discriminator, Generator
+from .models import VGG16, Discriminator, Generator, _class_index
 
 
 def _unwrap(module):
@@ -217,7 +217,9 @@ class ModelWrapper(object):
 
         Order of work (results identical to the reference's order): D phase; [D gradients -> side stream]; generator forward of
         the G phase (independent of D); join; Adam(D); rest of the G phase; [G gradients -> side stream]; join; Adam(G)."""
-        labels_f = labels.float()
+        # the one-hot labels become class indices ONCE per step (the reference's modules take the argmax in every forward,
+        # models.py:151,501: five reductions and a float copy per step; our modules pass indices through)
+        labels = labels_f = _class_index(labels)
         with profiling.range("D phase"):
             features_real, loss_d_real, loss_d_fake = self._d_phase(images_real, labels, labels_f, masks, noise_d)
             self._start_reduce("d", self._d_params, eager=True)
@@ -266,16 +268,15 @@ class ModelWrapper(object):
         try:
             gd = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gd):
-                labels_f = st["labels"].float()
-                feats, l_real, l_fake = self._d_phase(st["images"], st["labels"], labels_f, st["masks"], st["noise_d"])
+                cls = st["cls"] = _class_index(st["labels"])          # recomputed by every replay of this graph; the other two read it
+                feats, l_real, l_fake = self._d_phase(st["images"], cls, cls, st["masks"], st["noise_d"])
             st["d_grads"] = [p.grad for p in self._d_params]
             gf = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gf, pool=gd.pool()):
-                labels_f = st["labels"].float()
-                fake, _ = self._g_forward(st["images"], labels_f, st["masks"], feats, st["noise_g"])
+                fake, _ = self._g_forward(st["images"], cls, st["masks"], feats, st["noise_g"])
             gg = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gg, pool=gd.pool()):
-                l_g, l_rec, l_div = self._g_rest(fake, st["noise_g"], st["labels"], st["masks"], feats, w_rec, w_div)
+                l_g, l_rec, l_div = self._g_rest(fake, st["noise_g"], cls, st["masks"], feats, w_rec, w_div)
             st["g_grads"] = [p.grad for p in self._g_params]
         finally:
             self._capturing = False
