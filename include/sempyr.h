@@ -187,6 +187,15 @@ int sp_conv2d_wgrad_accum_pooled(const void* x, const void* dy, float* dw, float
                                  int32_t dtype, sp_stream_t stream);
 int sp_conv2d_wgrad_workspace(int32_t n, int32_t h, int32_t w_, int32_t cin_p, int32_t cout, int32_t ksize,
                               int32_t dtype, int64_t* floats_out);
+/* sp_conv2d_wgrad_accum for a two-group batch (sp_conv_params.img_scale; the discriminator's D(real) | D(fake) pass): images
+ * [0, split) accumulate into (dw_a, dbias_a), images [split, n) into (dw_b, dbias_b) - the spectral-norm backward of each forward
+ * needs ITS weight gradient.  dy_pooled != 0: dy is at the pooled resolution as in sp_conv2d_wgrad_accum_pooled.  Where the row-walking
+ * kernel takes the layer and the group boundary falls between two of its blocks this is ONE launch over all n images plus one
+ * reduce pass per group (half the partial-tile traffic of two launches); otherwise the two groups run one after the other.
+ * workspace: sp_conv2d_wgrad_workspace() floats for n images. */
+int sp_conv2d_wgrad_accum_pair(const void* x, const void* dy, float* dw_a, float* dbias_a, float* dw_b, float* dbias_b, float* workspace,
+                               int64_t workspace_floats, int32_t n, int32_t split, int32_t h, int32_t w_, int32_t cin_p, int32_t cout,
+                               int32_t ld_dy, int32_t ksize, int32_t dy_pooled, int32_t dtype, sp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Skinny linear layers: y = act(x W^T + bias + res), batch rows of any pitch, weights packed [n][kp]

@@ -179,6 +179,8 @@ int sp_conv_pp_launch(const sp_conv_params& p, int th, hipStream_t s);
 int sp_wgrad_rows_launch(const void* x, const void* dy, float* dw, float* dbias, int n, int h, int w, int cin, int cout,
                          int ld_dy, float* ws, long ws_floats, int dy_up2, hipStream_t s);
 long sp_wgrad_rows_workspace(int n, int h, int w, int cin, int cout);
+int sp_wgrad_rows_launch_pair(const void* x, const void* dy, float* dw_a, float* dbias_a, float* dw_b, float* dbias_b, int n, int split,
+                              int h, int w, int cin, int cout, int ld_dy, float* ws, long ws_floats, int dy_up2, hipStream_t s);
 // conv_wgrad_1x1.hip: same contract for the bf16 1x1 layers
 int sp_wgrad1x1_launch(const void* x, const void* dy, float* dw, float* dbias, int n, int h, int w, int cin, int cout, int ld_dy,
                        float* ws, long ws_floats, hipStream_t s);

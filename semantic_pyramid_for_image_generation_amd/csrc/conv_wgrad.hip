@@ -726,6 +726,35 @@ int dispatch_wgrad(const void* x, const void* dy, float* dw, int n, int h, int w
 
 }  // namespace
 
+extern "C" int sp_conv2d_wgrad_accum_pair(const void* x, const void* dy, float* dw_a, float* dbias_a, float* dw_b, float* dbias_b,
+                                          float* workspace, int64_t workspace_floats, int32_t n, int32_t split, int32_t h, int32_t w_,
+                                          int32_t cin_p, int32_t cout, int32_t ld_dy, int32_t ksize, int32_t dy_pooled, int32_t dtype,
+                                          sp_stream_t stream) {
+    SP_CHECK_ARG(x && dy && dw_a && dw_b && split > 0 && split < n, "sp_conv2d_wgrad_accum_pair: bad args");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == SP_BF16 && ksize == 3 && sp_tune(SP_TUNE_WGRAD_ROWS, 1)) {
+        // one launch of the row walker over both groups where the group boundary falls between two of its blocks
+        const int rc = sp_wgrad_rows_launch_pair(x, dy, dw_a, dbias_a, dw_b, dbias_b, n, split, h, w_, cin_p, cout, ld_dy, workspace, workspace_floats,
+                                                 dy_pooled ? 1 : 0, s);
+        if (rc != 1) return rc;
+    }
+    // everything else: the two groups one after the other (contiguous image ranges)
+    const long esz = dtype == SP_F32 ? 4 : 2;
+    const long xs = (long)h * w_ * cin_p * esz;
+    const long ds = (dy_pooled ? (long)(h / 2) * (w_ / 2) : (long)h * w_) * ld_dy * esz;
+    for (int g = 0; g < 2; ++g) {
+        const int n0 = g ? split : 0, ng = g ? n - split : split;
+        const char* xg = reinterpret_cast<const char*>(x) + n0 * xs;
+        const char* dg = reinterpret_cast<const char*>(dy) + n0 * ds;
+        const int rc = dy_pooled ? sp_conv2d_wgrad_accum_pooled(xg, dg, g ? dw_b : dw_a, g ? dbias_b : dbias_a, workspace, workspace_floats, ng, h, w_,
+                                                                cin_p, cout, ld_dy, ksize, dtype, stream)
+                                 : sp_conv2d_wgrad_accum(xg, dg, g ? dw_b : dw_a, g ? dbias_b : dbias_a, workspace, workspace_floats, ng, h, w_, cin_p, cout,
+                                                         ld_dy, ksize, dtype, stream);
+        if (rc != SP_OK) return rc;
+    }
+    return SP_OK;
+}
+
 extern "C" int sp_conv2d_wgrad_workspace(int32_t n, int32_t h, int32_t w_, int32_t cin_p, int32_t cout, int32_t ksize,
                                          int32_t dtype, int64_t* floats_out) {
     SP_CHECK_ARG(floats_out && n > 0 && h > 0 && w_ > 0 && cin_p > 0 && cout > 0 && (ksize == 1 || ksize == 3), "sp_conv2d_wgrad_workspace: bad args");

@@ -983,7 +983,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_pp3_kernel(WrArgs a, int rows_
 // dW through atomics.
 __global__ __launch_bounds__(256) void conv_wgrad_rows_reduce_kernel(const float* __restrict__ slabs, int nblk, float* __restrict__ dw,
                                                                      int CIN, int COUT, int ci_tiles, const float* __restrict__ bias_part,
-                                                                     float* __restrict__ dbias, int ordered) {
+                                                                     float* __restrict__ dbias, int ordered, int kbeg, int kend) {
+    // [kbeg, kend): the blocks (of every pair) whose partial tiles this launch adds - all of them, or the blocks that walked the rows
+    // of ONE group of a two-group batch (sp_wgrad_rows_launch_pair); nblk stays the number of slabs per pair (the slab stride)
     const int co0 = (blockIdx.y / ci_tiles) * 64, ci0 = (blockIdx.y % ci_tiles) * 64;
     if (bias_part != nullptr && blockIdx.z == 0 && ci0 == 0 && (!ordered || blockIdx.x == 0)) {
         // bias gradient: the per-block partial sums of this co tile, split over the gridDim.x blocks of the pair and the four
@@ -995,7 +997,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_reduce_kernel(const float
         // ordered: block 0 of the pair alone sums all partials (fixed order) and is the only writer of its dbias entries
         const int kstep = ordered ? 4 : gridDim.x * 4;
 #pragma unroll 8
-        for (int k = (ordered ? 0 : blockIdx.x * 4) + grp; k < nblk; k += kstep) t += bp[(long)k * 64];
+        for (int k = kbeg + (ordered ? 0 : blockIdx.x * 4) + grp; k < kend; k += kstep) t += bp[(long)k * 64];
         bred[threadIdx.x] = t;
         __syncthreads();
         if (threadIdx.x < 64 && co0 + col < COUT) {
@@ -1007,11 +1009,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_reduce_kernel(const float
     const int e4 = blockIdx.x * 256 + threadIdx.x;                 // float4 index inside the tile: [tap][co][ci / 4]
     if (e4 >= 9 * 64 * 16) return;
     const int t = e4 / (64 * 16), co = co0 + (e4 / 16) % 64, ci = ci0 + (e4 % 16) * 4;
-    if (co >= COUT || ci >= CIN || (int)blockIdx.z >= nblk) return;
-    float4 s = reinterpret_cast<const float4*>(base + (long)blockIdx.z * (9 * 64 * 64))[e4];
+    if (co >= COUT || ci >= CIN || kbeg + (int)blockIdx.z >= kend) return;
+    float4 s = reinterpret_cast<const float4*>(base + (long)(kbeg + blockIdx.z) * (9 * 64 * 64))[e4];
     // (unrolled: the loads of eight slabs fly together - the plain loop waited for each: 17 us per launch for 75 MB)
 #pragma unroll 8
-    for (int k = blockIdx.z + gridDim.z; k < nblk; k += gridDim.z) {
+    for (int k = kbeg + blockIdx.z + gridDim.z; k < kend; k += gridDim.z) {
         const float4 v = reinterpret_cast<const float4*>(base + (long)k * (9 * 64 * 64))[e4];
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
@@ -1118,7 +1120,7 @@ int sp_wgrad_rows_launch(const void* x, const void* dy, float* dw, float* dbias,
             int z = 512 / (36 * pairs);
             if (z > nb / 4) z = nb / 4;
             if (z < 1 || det) z = 1;
-            hipLaunchKernelGGL(conv_wgrad_rows_reduce_kernel, dim3(9 * 64 * 16 / 256, (unsigned)pairs, (unsigned)z), dim3(256), 0, s, ws, nb, dw, cin, cout, a.ci_tiles, a.bias_part, dbias, det ? 1 : 0);
+            hipLaunchKernelGGL(conv_wgrad_rows_reduce_kernel, dim3(9 * 64 * 16 / 256, (unsigned)pairs, (unsigned)z), dim3(256), 0, s, ws, nb, dw, cin, cout, a.ci_tiles, a.bias_part, dbias, det ? 1 : 0, 0, nb);
         }
         SP_LAUNCH_CHECK();
         return SP_OK;
@@ -1144,7 +1146,63 @@ int sp_wgrad_rows_launch(const void* x, const void* dy, float* dw, float* dbias,
         int z = 512 / (36 * pairs);                       // ~512 reducer blocks
         if (z > nblk / 4) z = nblk / 4;
         if (z < 1 || det) z = 1;                          // deterministic mode: one ordered chain per element, no atomics
-        hipLaunchKernelGGL(conv_wgrad_rows_reduce_kernel, dim3(9 * 64 * 16 / 256, (unsigned)pairs, (unsigned)z), dim3(256), 0, s, ws, nblk, dw, cin, cout, a.ci_tiles, a.bias_part, dbias, det ? 1 : 0);
+        hipLaunchKernelGGL(conv_wgrad_rows_reduce_kernel, dim3(9 * 64 * 16 / 256, (unsigned)pairs, (unsigned)z), dim3(256), 0, s, ws, nblk, dw, cin, cout, a.ci_tiles, a.bias_part, dbias, det ? 1 : 0, 0, nblk);
+    }
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+// Two-group batch (sp_conv2d_wgrad_accum_pair): images [0, split) accumulate into (dw_a, dbias_a), the rest into (dw_b, dbias_b) -
+// ONE launch of the ping-pong row walker over all n images (a block walks a contiguous range of image rows, so when the group
+// boundary falls between two blocks every partial tile belongs to one group) and one reduce pass per group over that group's
+// slabs.  Returns SP_OK after launching, 1 if the shape / plan is not covered (the caller then runs the two groups separately).
+int sp_wgrad_rows_launch_pair(const void* x, const void* dy, float* dw_a, float* dbias_a, float* dw_b, float* dbias_b, int n, int split,
+                              int h, int w, int cin, int cout, int ld_dy, float* ws, long ws_floats, int dy_up2, hipStream_t s) {
+    if (wr_narrow(h, w, dy_up2) != 0 || h % WR_R != 0 || sp_tune(SP_TUNE_WGRAD_PP, 1) != 1 || split <= 0 || split >= n) return 1;
+    if ((dbias_a == nullptr) != (dbias_b == nullptr)) return 1;
+    if ((long)n * h * w * cin * 2 >= (1L << 30) || (long)n * h * w * ld_dy * 2 >= (1L << 30)) return 1;
+    const bool det = sp_deterministic(SP_BF16);
+    const int env_slabs = det ? 1 : sp_tune(SP_TUNE_WGRAD_ROWS_SLABS, 1);
+    const int co_tiles = (cout + 63) / 64, ci_tiles = (cin + 63) / 64, pairs = co_tiles * ci_tiles;
+    if (!(env_slabs == 1 && ws != nullptr && ws_floats >= 512L * (9 * 64 * 64 + 64) && cin % 4 == 0)) return 1;
+    const int strips = w / 32;
+    const int rows_total = n * strips * h;
+    int nb = 256 / pairs;
+    if (nb < 1) nb = 1;
+    int rpb = (rows_total + nb - 1) / nb;
+    if (rpb < 8) rpb = rows_total < 8 ? rows_total : 8;
+    nb = (rows_total + rpb - 1) / rpb;
+    const long boundary = (long)split * strips * h;                     // first flattened row of the second group
+    if (boundary % rpb != 0 || (long)nb * pairs > 512) return 1;
+    const int kb = (int)(boundary / rpb);
+    WrArgs a;
+    a.x = reinterpret_cast<const bf16*>(x);
+    a.dy = reinterpret_cast<const bf16*>(dy);
+    a.dw = dw_a;
+    a.dbias = dbias_a;                                                   // (with slabs: only its being non-null matters)
+    a.N = n; a.H = h; a.W = w; a.CIN = cin; a.COUT = cout; a.LD_DY = ld_dy;
+    a.dy_up2 = dy_up2;
+    a.thin_mode = 0;
+    a.ci_tiles = ci_tiles;
+    a.rows_per_unit = h;
+    a.units = n * strips;
+    a.slabs = ws;
+    a.bias_part = dbias_a != nullptr ? ws + 512L * 9 * 64 * 64 : nullptr;
+    static bool pp_attr = false;
+    if (!pp_attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_pp3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WP3_LDS);
+        if (e != hipSuccess) { sp_set_error("hipFuncSetAttribute(LDS=%d) failed: %s", WP3_LDS, hipGetErrorString(e)); return SP_ERR_LAUNCH; }
+        pp_attr = true;
+    }
+    sp_note_route("conv_wgrad_pp3 (row walker, ping-pong, two groups) + 2 x rows_reduce");
+    hipLaunchKernelGGL(conv_wgrad_pp3_kernel<false>, dim3((unsigned)nb, (unsigned)pairs), dim3(512), WP3_LDS, s, a, rpb, rows_total);
+    for (int grp = 0; grp < 2; ++grp) {
+        const int k0 = grp ? kb : 0, k1 = grp ? nb : kb;
+        int z = 512 / (36 * pairs);
+        if (z > (k1 - k0) / 4) z = (k1 - k0) / 4;
+        if (z < 1 || det) z = 1;
+        hipLaunchKernelGGL(conv_wgrad_rows_reduce_kernel, dim3(9 * 64 * 16 / 256, (unsigned)pairs, (unsigned)z), dim3(256), 0, s, ws, nb, grp ? dw_b : dw_a,
+                           cin, cout, ci_tiles, a.bias_part, grp ? dbias_b : dbias_a, det ? 1 : 0, k0, k1);
     }
     SP_LAUNCH_CHECK();
     return SP_OK;

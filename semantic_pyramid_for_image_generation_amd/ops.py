@@ -782,25 +782,23 @@ class _ConvFn(torch.autograd.Function):
             pair = ctx.pair
             if not pair.call_a.bank.direct_grads:
                 raise L.SempyrError("a two-group pass needs the bank's direct gradients (ModelWrapper sets them up)")
-            for call, lo, hi in ((pair.call_a, 0, pair.split), (pair.call_b, pair.split, n)):
-                if hi <= lo:
-                    continue
-                plg = call.layers[pl.slot]
-                dwsn = call.dw_slot(plg)
-                dbg = call.db_slot(plg) if bias_needed(need, 2) else None
-                xg, dzg, ng = x.narrow(0, lo, hi - lo), dz.narrow(0, lo, hi - lo), hi - lo
-                wsg = wgrad_workspace_floats(ng, h, w, cin_p, cout, ksize, dt)
-                if up2 and wsg == 0:
-                    raise L.SempyrError("pooled weight gradient without a workspace plan for a group of %d images" % ng)
-                ws = torch.empty(wsg, dtype=torch.float32, device=x.device) if wsg else None
+            pa, pb = pair.call_a.layers[pl.slot], pair.call_b.layers[pl.slot]
+            dwa, dwb = pair.call_a.dw_slot(pa), pair.call_b.dw_slot(pb)
+            want_bias = bias_needed(need, 2)
+            dba = pair.call_a.db_slot(pa) if want_bias else None
+            dbb = pair.call_b.db_slot(pb) if want_bias else None
+            wsg = wgrad_workspace_floats(n, h, w, cin_p, cout, ksize, dt)
+            ws = torch.empty(wsg, dtype=torch.float32, device=x.device) if wsg else None
 
-                def launch_wgrad(xg=xg, dzg=dzg, dwsn=dwsn, dbg=dbg, ws=ws, wsg=wsg, ng=ng):
-                    L.call("sp_conv2d_wgrad_accum_pooled" if up2 else "sp_conv2d_wgrad_accum", ptr(xg), ptr(dzg), ptr(dwsn), ptr(dbg), ptr(ws),
-                           wsg, ng, h, w, cin_p, cout, cout_p, ksize, sp_dtype(dt), stream())
-                if KERNEL_PROBE is not None:
-                    _probed("wgrad", 2.0 * ng * h * w * cin_p * cout * ksize * ksize, False, launch_wgrad, (ksize, cin_p, cout, h, w, ng))
-                else:
-                    launch_wgrad()
+            def launch_wgrad():
+                # ONE launch over both groups where the row walker takes the layer (half the partial-tile traffic), else the two
+                # groups one after the other - decided inside the library (include/sempyr.h: sp_conv2d_wgrad_accum_pair)
+                L.call("sp_conv2d_wgrad_accum_pair", ptr(x), ptr(dz), ptr(dwa), ptr(dba), ptr(dwb), ptr(dbb), ptr(ws), wsg, n, pair.split, h, w,
+                       cin_p, cout, cout_p, ksize, 1 if up2 else 0, sp_dtype(dt), stream())
+            if KERNEL_PROBE is not None:
+                _probed("wgrad", 2.0 * n * h * w * cin_p * cout * ksize * ksize, False, launch_wgrad, (ksize, cin_p, cout, h, w, n))
+            else:
+                launch_wgrad()
             dh = dhb = _zero1(x.device)
         elif need[1]:
             # weight (+ bias) gradient accumulate into this layer's slots of the pass-wide arena; the spectral-norm
