@@ -60,7 +60,8 @@ struct PPGeom {
     static constexpr int OFF_W = 2 * HALO_BUF, OFF_BIAS = OFF_W + NWS * W_BYTES, OFF_SCALE = OFF_BIAS + PP_BIAS_MAX * 4;
     static constexpr int OFF_DUMMY = OFF_SCALE + (F8 ? PP_BIAS_MAX * 4 : 0);
     static constexpr int OFF_TAIL = OFF_DUMMY + 1024;                 // fused 1x1 tail (sp_conv_params.tail_w): [4][64] weights + [4] bias, fp32
-    static constexpr int LDS = OFF_TAIL + (WCO == 1 && FW == 2 && !F8 ? 4 * 64 * 4 + 16 : 0);
+    static constexpr int LDS_TAIL = OFF_TAIL + 4 * 64 * 4 + 16;       // the TAIL instantiation's size
+    static constexpr int LDS = OFF_TAIL;
 };
 
 // number of (halo row h', tap row dr') MFMA groups that precede group (h, dr) in the MFMA segment's order (h outer, dr inner)
@@ -78,8 +79,9 @@ constexpr int pp_group_index(int h, int dr, int rw) {
 // tanh.  The general epilogue (per-lane `wide` test, 4-channel and scalar tails, pooling, an inlined tanh per value and call site) is
 // 18 K instructions in ~1 100 basic blocks around a 1.7 K-instruction loop; measured with compile-time assumptions in its place
 // (scratch: -DPP_ASSUME_SIMPLE), a launch of 128->128 @128^2 drops from 170 K to 148 K cycles per block, 64->128 from 111 K to 92 K.
-template <typename T, int WCO, int PRIO, bool TIMING = false, bool DMA_IN_L = true, bool FAST = false, int FW = 2>
+template <typename T, int WCO, int PRIO, bool TIMING = false, bool DMA_IN_L = true, bool FAST = false, int FW = 2, bool TAIL = false>
 __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int cotiles, int total, int prio) {
+    static_assert(!TAIL || (FAST && WCO == 1 && FW == 2), "the fused 1x1 tail lives in the 64-channel FAST form");
     using G = PPGeom<T, WCO, FW>;
     static_assert(FW == 2 || (sizeof(T) == 2 && FAST), "16-wide tiles: bf16, FAST epilogue (no pooling)");
     constexpr int PP_TW = G::TW;
@@ -109,7 +111,8 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
         float* bias_l = reinterpret_cast<float*>(smem + G::OFF_BIAS);
         const int nb = cotiles * CO_T < PP_BIAS_MAX ? cotiles * CO_T : PP_BIAS_MAX;
         for (int i = tid; i < nb; i += 512) bias_l[i] = (p.bias != nullptr && i < p.cout) ? p.bias[i] : 0.f;
-        if constexpr (FAST && WCO == 1 && FW == 2) {
+        if constexpr (TAIL) {                                // (its own instantiation: compiled into the plain FAST form it cost every
+                                                             // launch of the 64-channel kernel 4 %)
             if (p.tail_w != nullptr) {                       // fused 1x1 tail: weights [tail_cout][64] (16-bit, the 1x1 layer's forward packing) -> fp32
                 float* tail_l = reinterpret_cast<float*>(smem + G::OFF_TAIL);
                 const T* tw = reinterpret_cast<const T*>(p.tail_w);
@@ -455,7 +458,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) acc[i][jj][r] = fmaxf(acc[i][jj][r], 0.f);
                     }
-                    if constexpr (WCO == 1 && FW == 2) {
+                    if constexpr (TAIL) {
                         // fused 1x1 tail (the generator's last two layers, models.py:55-61: conv3x3 -> LeakyReLU -> conv1x1 -> tanh): the 64
                         // channels of a pixel sit in the four lanes l, l + 16, l + 32, l + 48 - each takes the dot products of its 16
                         // channels with the tail's rows (LDS copy), two butterfly steps add them up, lane group 0 stores the pixel's
@@ -652,16 +655,17 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
     }
 }
 
-template <typename T, int WCO, int PRIO, bool TIMING = false, bool DMA_IN_L = true, bool FAST = false, int FW = 2>
+template <typename T, int WCO, int PRIO, bool TIMING = false, bool DMA_IN_L = true, bool FAST = false, int FW = 2, bool TAIL = false>
 int launch_pp(const sp_conv_params& p, int prio, hipStream_t s) {
     using G = PPGeom<T, WCO, FW>;
     constexpr int TH = G::TH;
-    static_assert(G::LDS <= 163840, "LDS budget");
+    constexpr int LDS_BYTES = TAIL ? G::LDS_TAIL : G::LDS;
+    static_assert(LDS_BYTES <= 163840, "LDS budget");
     static bool attr_set = false;
-    auto kern = conv3x3_pp_kernel<T, WCO, PRIO, TIMING, DMA_IN_L, FAST, FW>;
+    auto kern = conv3x3_pp_kernel<T, WCO, PRIO, TIMING, DMA_IN_L, FAST, FW, TAIL>;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-        if (e != hipSuccess) { sp_set_error("hipFuncSetAttribute(LDS=%d) failed: %s", G::LDS, hipGetErrorString(e)); return SP_ERR_LAUNCH; }
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) { sp_set_error("hipFuncSetAttribute(LDS=%d) failed: %s", LDS_BYTES, hipGetErrorString(e)); return SP_ERR_LAUNCH; }
         attr_set = true;
     }
     const int cotiles = (p.cout + G::CO_T - 1) / G::CO_T;
@@ -670,7 +674,7 @@ int launch_pp(const sp_conv_params& p, int prio, hipStream_t s) {
     if (grid >= 8) grid -= grid % 8;
     sp_note_route(G::F8 ? "conv3x3_pp<f8,2>" : FW == 1 ? "conv3x3_pp<16bit,2,FAST,w16>" : WCO == 2 ? (FAST ? "conv3x3_pp<16bit,2,FAST>" : "conv3x3_pp<16bit,2>")
                                                                                   : (FAST ? "conv3x3_pp<16bit,1,FAST>" : "conv3x3_pp<16bit,1>"));
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), G::LDS, s, p, cotiles, total, prio);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), LDS_BYTES, s, p, cotiles, total, prio);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }
@@ -704,7 +708,10 @@ int sp_conv_pp_launch(const sp_conv_params& p, int th, hipStream_t s) {
     // bit 4 = the general epilogue everywhere
     const int prio = sp_tune(SP_TUNE_CONV_PP_PRIO, 1);
     const bool fast = !(prio & 16) && p.pool2 == 0 && (p.cout & 15) == 0 && (p.ldy & 7) == 0 && p.act != SP_ACT_TANH;
-    if (p.tail_w != nullptr && !(th == 16 && p.cout == 64 && fast)) return 1;      // the fused 1x1 tail lives in the 64-channel FAST form only
+    if (p.tail_w != nullptr) {                             // the fused 1x1 tail: its own instantiation of the 64-channel FAST form
+        if (!(th == 16 && p.cout == 64 && fast)) return 1;
+        return launch_pp<bf16, 1, 1, false, true, true, 2, true>(p, prio, s);
+    }
     if (th == 16 && p.cout <= 64)                          // 64 co x 16x32 px
         return fast ? launch_pp<bf16, 1, 1, false, true, true>(p, prio, s) : launch_pp<bf16, 1, 1>(p, prio, s);
     if (th != 8 || p.cout <= 64) return 1;
