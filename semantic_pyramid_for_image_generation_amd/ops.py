@@ -252,6 +252,8 @@ class _SNBankFn(torch.autograd.Function):
         n = hi - lo
         if call.arena is None:
             return (None,) * (n + 2)
+        if CFG.wgrad_side_stream:
+            join_wgrad_stream(call.arena.device)          # weight-gradient launches that ran on the side stream wrote the arena
         table = ctypes.c_void_p(bank.bwd_table_dev.data_ptr() + lo * ctypes.sizeof(L.SpSnBwdLayer))
         dots = torch.empty(n * 512, dtype=torch.float32, device=call.arena.device)     # per-block partial <dW, W> sums
         start, stop = bank.group_range[g]
@@ -698,6 +700,33 @@ def wgrad_workspace_floats(n, h, w, cin_p, cout, ksize, dtype) -> int:
     return v
 
 
+_WGRAD_STREAMS = {}
+
+
+def _on_wgrad_stream(launch, tensors) -> None:
+    """Experiment (config.CFG.wgrad_side_stream, off by default): the weight gradient of a layer depends on nothing the rest of the
+    backward pass waits for (its results are read by the batched spectral-norm backward at the very end), so it can run on a SIDE
+    stream - a parallel branch of the captured graph - and fill the CUs the input-gradient launches leave idle in their last round.
+    `tensors`: everything the launch reads or writes that was allocated on the current stream."""
+    dev = tensors[0].device
+    main = torch.cuda.current_stream(dev)
+    side = _WGRAD_STREAMS.get(dev)
+    if side is None:
+        side = _WGRAD_STREAMS[dev] = torch.cuda.Stream(dev)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        launch()
+    for t in tensors:
+        if t is not None:
+            t.record_stream(side)
+
+
+def join_wgrad_stream(device) -> None:
+    side = _WGRAD_STREAMS.get(device)
+    if side is not None:
+        torch.cuda.current_stream(device).wait_stream(side)
+
+
 class PairPass:
     """Two forwards of one network whose convolution trunk runs as ONE batch of two groups (the discriminator's D(real) and
     D(fake) of a step, model_wrapper.py:153-155): images [0, split) belong to forward `a`, the rest to forward `b`, which ran one
@@ -797,6 +826,8 @@ class _ConvFn(torch.autograd.Function):
                        cin_p, cout, cout_p, ksize, 1 if up2 else 0, sp_dtype(dt), stream())
             if KERNEL_PROBE is not None:
                 _probed("wgrad", 2.0 * n * h * w * cin_p * cout * ksize * ksize, False, launch_wgrad, (ksize, cin_p, cout, h, w, n))
+            elif CFG.wgrad_side_stream:
+                _on_wgrad_stream(launch_wgrad, [x, dz, ws])
             else:
                 launch_wgrad()
             dh = dhb = _zero1(x.device)
@@ -813,6 +844,8 @@ class _ConvFn(torch.autograd.Function):
                        ws_floats, n, h, w, cin_p, cout, cout_p, ksize, sp_dtype(dt), stream())
             if KERNEL_PROBE is not None:
                 _probed("wgrad", 2.0 * n * h * w * cin_p * cout * ksize * ksize, False, launch_wgrad, (ksize, cin_p, cout, h, w, n))
+            elif CFG.wgrad_side_stream and pl.call.bank.direct_grads:
+                _on_wgrad_stream(launch_wgrad, [x, dz, ws])
             else:
                 launch_wgrad()
             dh = _zero1(x.device)
