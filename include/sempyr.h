@@ -397,6 +397,13 @@ int sp_act_bwd(const void* dy, const void* y, void* dz, int64_t pixels, int32_t 
                int32_t dtype, sp_stream_t stream);
 int sp_scale_add(const void* a, const void* b, const float* g, void* y, int64_t numel, int32_t dtype,
                  sp_stream_t stream);
+/* y[row][c] = (x[row][c] - bias[c]) * (sig_a[0] * sig_b[1]) + bias[c]: the output of a spectral-normalised layer re-expressed under
+ * the sigma of ANOTHER forward of the same weights - conv(x, W / sigma_b) + b from conv(x, W / sigma_a) + b without running the layer
+ * again.  The generator's masked-feature mappings (models.py:78-94) see the same pyramid, masks and weight_orig in both generator
+ * forwards of a step (model_wrapper.py:147-151,168-172); only the power iteration has advanced.  sig_a / sig_b: DEVICE pointers to
+ * the {sigma, 1 / sigma} pairs in the two sp_sn_forward scratches; rows x c elements, pitches ldx / ldy; bias may be NULL. */
+int sp_rescale_bias(const void* x, void* y, int64_t rows, int32_t c, int32_t ldx, int32_t ldy, const float* bias, const float* sig_a,
+                    const float* sig_b, int32_t dtype, sp_stream_t stream);
 /* dg[0] = <dy, a>: per-block partial sums in `partials` (512 floats of scratch), added in block order by a second kernel */
 int sp_scale_add_bwd(const void* dy, const void* a, const float* g, void* da, float* dg, float* partials, int64_t numel,
                      int32_t dtype, sp_stream_t stream);

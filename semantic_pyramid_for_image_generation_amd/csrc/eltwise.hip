@@ -138,6 +138,36 @@ __global__ void scale_add_kernel(const T* __restrict__ a, const T* __restrict__ 
     }
 }
 
+// ---- y = (x - bias[c]) * (sigma_a / sigma_b) + bias[c]: the output of a spectral-normalised layer under ANOTHER forward's sigma -----
+// (conv(x, W / sigma_b) + b = (conv(x, W / sigma_a) + b - b) * sigma_a / sigma_b + b: the layer is not run again, sp_rescale_bias)
+template <typename T>
+__global__ void rescale_bias_kernel(const T* __restrict__ x, T* __restrict__ y, long rows, int c, int ldx, int ldy,
+                                    const float* __restrict__ bias, const float* __restrict__ sig_a, const float* __restrict__ sig_b) {
+    const float r = sig_a[0] * sig_b[1];                    // {sigma, 1 / sigma} pairs of the two forwards
+    const int c4 = c / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows * c4; i += (long)gridDim.x * 256) {
+        const long row = i / c4;
+        const int col = (int)(i - row * c4) * 4;
+        float v[4];
+        Elem<T>::ld4(x + row * ldx + col, v);
+        const float4 bv = bias != nullptr ? *reinterpret_cast<const float4*>(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[0] = (v[0] - bv.x) * r + bv.x; v[1] = (v[1] - bv.y) * r + bv.y; v[2] = (v[2] - bv.z) * r + bv.z; v[3] = (v[3] - bv.w) * r + bv.w;
+        Elem<T>::st4(y + row * ldy + col, v);
+    }
+}
+
+template <typename T>
+__global__ void rescale_bias_scalar_kernel(const T* __restrict__ x, T* __restrict__ y, long rows, int c, int ldx, int ldy,
+                                           const float* __restrict__ bias, const float* __restrict__ sig_a, const float* __restrict__ sig_b) {
+    const float r = sig_a[0] * sig_b[1];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows * c; i += (long)gridDim.x * 256) {
+        const long row = i / c;
+        const int col = (int)(i - row * c);
+        const float bv = bias != nullptr ? bias[col] : 0.f;
+        Elem<T>::st(y + row * ldy + col, (Elem<T>::ld(x + row * ldx + col) - bv) * r + bv);
+    }
+}
+
 template <typename T>
 __global__ void scale_add_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ a, const float* __restrict__ g,
                                      T* __restrict__ da, float* __restrict__ dg_part, long n4) {
@@ -325,6 +355,26 @@ extern "C" int sp_scale_add(const void* a, const void* b, const float* g, void* 
     SP_DT_SWITCH(dtype,
                  hipLaunchKernelGGL(scale_add_kernel<float>, dim3(gr), dim3(256), 0, s, (const float*)a, (const float*)b, g, (float*)y, (long)(numel / 4)),
                  hipLaunchKernelGGL(scale_add_kernel<bf16>, dim3(gr), dim3(256), 0, s, (const bf16*)a, (const bf16*)b, g, (bf16*)y, (long)(numel / 4)));
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_rescale_bias(const void* x, void* y, int64_t rows, int32_t c, int32_t ldx, int32_t ldy, const float* bias,
+                               const float* sig_a, const float* sig_b, int32_t dtype, sp_stream_t stream) {
+    SP_CHECK_ARG(x && y && sig_a && sig_b && rows > 0 && c > 0 && ldx >= c && ldy >= c, "sp_rescale_bias: bad args");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if ((c & 3) || (ldx & 3) || (ldy & 3)) {                 // odd widths (the 365-wide linear mapping): element by element
+        const int g1 = grid_for(rows * c);
+        SP_DT_SWITCH(dtype,
+                     hipLaunchKernelGGL(rescale_bias_scalar_kernel<float>, dim3(g1), dim3(256), 0, s, (const float*)x, (float*)y, (long)rows, c, ldx, ldy, bias, sig_a, sig_b),
+                     hipLaunchKernelGGL(rescale_bias_scalar_kernel<bf16>, dim3(g1), dim3(256), 0, s, (const bf16*)x, (bf16*)y, (long)rows, c, ldx, ldy, bias, sig_a, sig_b));
+        SP_LAUNCH_CHECK();
+        return SP_OK;
+    }
+    const int gr = grid_for(rows * (c / 4));
+    SP_DT_SWITCH(dtype,
+                 hipLaunchKernelGGL(rescale_bias_kernel<float>, dim3(gr), dim3(256), 0, s, (const float*)x, (float*)y, (long)rows, c, ldx, ldy, bias, sig_a, sig_b),
+                 hipLaunchKernelGGL(rescale_bias_kernel<bf16>, dim3(gr), dim3(256), 0, s, (const bf16*)x, (bf16*)y, (long)rows, c, ldx, ldy, bias, sig_a, sig_b));
     SP_LAUNCH_CHECK();
     return SP_OK;
 }

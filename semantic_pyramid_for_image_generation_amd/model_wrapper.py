@@ -167,6 +167,8 @@ class ModelWrapper(object):
             features_real = V(images_real)
             if noise_d is None:
                 noise_d = torch.randn((images_real.shape[0], self.latent_dimensions), dtype=torch.float32, device=images_real.device)
+            if hasattr(G, "map_mode"):
+                G.map_mode = "stash"                  # this forward and the G step's see the same pyramid, masks and weights
             images_fake = G(input=noise_d, features=features_real, masks=masks, class_id=labels_f)
         if CFG.d_pair and hasattr(D, "forward_pair") and D.training and images_fake.shape == images_real.shape:
             prediction_real, prediction_fake = D.forward_pair(images_real, images_fake, labels)     # one trunk pass over 2B images
@@ -186,6 +188,8 @@ class ModelWrapper(object):
         G.zero_grad()
         if noise_g is None:
             noise_g = torch.randn((images_real.shape[0], self.latent_dimensions), dtype=torch.float32, device=images_real.device)
+        if hasattr(G, "map_mode"):
+            G.map_mode = "reuse"                      # the masked-feature mappings come from the D step's forward (other sigma only)
         return G(input=noise_g, features=features_real, masks=masks, class_id=labels_f), noise_g
 
     def _g_rest(self, images_fake, noise_g, labels, masks, features_real, w_rec, w_div):

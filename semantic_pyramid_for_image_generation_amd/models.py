@@ -118,6 +118,8 @@ _FUSE_UPSAMPLE_BN = CFG.fuse_upsample_bn
 # (one block per CU walks the work items), so a second kernel on some CUs delays those blocks and with them the whole launch.
 # Off by default; SP_SIDE_FEATURES=1 for A/B runs.
 _SIDE_FEATURES = CFG.side_features
+# The second generator forward of a step derives its masked-feature mappings from the first one's (Generator._feature_maps_of_the_step).
+_REUSE_FEATURE_MAPS = CFG.reuse_feature_maps
 
 
 def init_weights(module: nn.Module) -> None:
@@ -336,6 +338,44 @@ class Generator(nn.Module):
         self._bn_list = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
         self._nbt_flat = None
         self._side_streams = {}
+        self.map_mode = None               # "stash" / "reuse": set by ModelWrapper for the next forward (_feature_maps_of_the_step)
+        self._map_stash = None
+
+    def _feature_maps_of_the_step(self, features, masks):
+        """The seven masked-feature mappings (models.py:78-94) see the SAME pyramid, masks and weight_orig in both generator forwards
+        of a training step (model_wrapper.py:147-151 without gradient, :168-172 with): only sigma differs, because every forward
+        advances the power iteration.  ModelWrapper announces the first forward (map_mode = "stash": the masked inputs, the outputs
+        and the packed layers are kept) and the second (map_mode = "reuse"): conv(x, W / sigma_2) + b = (conv(x, W / sigma_1) + b - b)
+        * sigma_1 / sigma_2 + b - one elementwise pass per mapping instead of five 3x3 convolutions, two linear layers and the seven
+        masking passes; the weight gradients of the second forward are taken from the stashed inputs as usual (ops._ReusedLayerFn).
+        Anything that does not match the stash (other tensors, shapes, dtype) falls back to computing the mappings."""
+        mode, self.map_mode = self.map_mode, None
+        if mode not in ("stash", "reuse") or not _REUSE_FEATURE_MAPS:
+            self._map_stash = None
+            return {}
+        blocks = [(self.linear_block_1, True), (self.linear_block_2, True)] + [(m, False) for m in self.main_path
+                                                                               if isinstance(m, GeneratorResidualBlock)]
+        key = (ops.compute_dtype(),) + tuple((f.data_ptr(), tuple(f.shape)) for f in features) + tuple((m.data_ptr(), tuple(m.shape)) for m in masks)
+        depth = len(features) - 1
+        out = {}
+        if mode == "reuse":
+            stash, self._map_stash = self._map_stash, None
+            if stash is None or stash["key"] != key:
+                return {}
+            for (block, _), (src, f, pl) in zip(blocks, stash["maps"]):
+                out[depth] = (lambda block=block, src=src, f=f, pl=pl: ops.reused_layer(block.masked_feature_mapping, src, f, pl))
+                depth -= 1
+            return out
+        maps = []
+        for block, is_linear in blocks:
+            src = ops.mask_mul_2d(features[depth], masks[depth]) if is_linear else ops.mask_concat(features[depth], masks[depth])
+            layer = block.masked_feature_mapping
+            f = layer(src)
+            maps.append((src, f.detach(), ops.packed_layer(layer, layer.training, f.dtype, f.device)))
+            out[depth] = (lambda f=f: f)
+            depth -= 1
+        self._map_stash = {"key": key, "maps": maps}
+        return out
 
     def _map_features_ahead(self, features, masks):
         """The seven masked-feature mappings (models.py:78-94: mask * feature [cat mask] -> spectral-norm linear / 3x3 convolution)
@@ -395,7 +435,7 @@ class Generator(nn.Module):
                 _COUNTERS_TICKED[0] = True
             cls = _class_index(class_id)
             depth = len(features) - 1
-            mapped = self._map_features_ahead(features, masks) if _SIDE_FEATURES else {}
+            mapped = self._map_features_ahead(features, masks) if _SIDE_FEATURES else self._feature_maps_of_the_step(features, masks)
             # the latent's requires_grad (model_wrapper.py:148) is a dead gradient: detach
             x = self.linear_layer(ops.as_rows(input.detach(), dt), ACT_LRELU)
             x = self.linear_block_1(x, None if depth in mapped else ops.mask_mul_2d(features[depth], masks[depth]), ACT_LRELU, True,

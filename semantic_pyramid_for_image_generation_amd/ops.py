@@ -918,6 +918,73 @@ def sn_conv2d_tail(x, m3, act3: int, m1, act1: int) -> torch.Tensor:
     return y
 
 
+class _ReusedLayerFn(torch.autograd.Function):
+    """The output of a spectral-normalised conv3x3 / linear layer for the forward in flight, derived from the SAME layer's output
+    of an earlier forward on the same input and the same weight_orig (sp_rescale_bias: only sigma has moved on).  The backward is
+    the layer's own - weight and bias gradients from the saved input into the current forward's arena; the input needs none."""
+
+    @staticmethod
+    def forward(ctx, handle, bias, x_saved, y_prev, pl_prev: PackedLayer, pl: PackedLayer, ksize: int, cout: int):
+        require_gpu(y_prev)
+        sig_prev = ctypes.c_void_p(pl_prev.scratch + 4 * (pl_prev.cols + 2 * pl_prev.rows))
+        sig_now = ctypes.c_void_p(pl.scratch + 4 * (pl.cols + 2 * pl.rows))
+        y = torch.empty_like(y_prev)
+        if y_prev.dim() == 4:
+            n, h, w, c = dims(y_prev)
+            rows, ld = n * h * w, c
+        else:
+            rows, c = y_prev.shape
+            ld = y_prev.stride(0)
+        L.call("sp_rescale_bias", ptr(y_prev), ptr(y), rows, c, ld, y.stride(0) if y.dim() == 2 else c, ptr(bias), sig_prev, sig_now,
+               sp_dtype(y_prev.dtype), stream())
+        ctx.pl, ctx.ksize, ctx.cout, ctx.keep = pl, ksize, cout, pl_prev.keep
+        ctx.save_for_backward(x_saved)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        pl, ksize, cout = ctx.pl, ctx.ksize, ctx.cout
+        need = ctx.needs_input_grad
+        dt = x.dtype
+        if not need[0]:
+            return (None,) * 8
+        dwsn = pl.call.dw_slot(pl)
+        db = pl.call.db_slot(pl) if need[1] else None
+        if x.dim() == 4:
+            dy = as_nhwc(dy, dt)
+            n, h, w, cin_p = dims(x)
+            cout_p = pad_channels(cout, dt)
+            if cout_p != cout:
+                raise L.SempyrError("a reused layer needs an unpadded channel count")
+            ws_floats = wgrad_workspace_floats(n, h, w, cin_p, cout, ksize, dt)
+            ws = torch.empty(ws_floats, dtype=torch.float32, device=x.device) if ws_floats else None
+
+            def launch():
+                L.call("sp_conv2d_wgrad_accum", ptr(x), ptr(dy), ptr(dwsn), ptr(db), ptr(ws), ws_floats, n, h, w, cin_p, cout, cout_p, ksize,
+                       sp_dtype(dt), stream())
+            if KERNEL_PROBE is not None:
+                _probed("wgrad", 2.0 * n * h * w * cin_p * cout * ksize * ksize, False, launch, (ksize, cin_p, cout, h, w, n))
+            else:
+                launch()
+        else:
+            dy = as_rows(dy, dt)
+            b, k = x.shape
+            if db is None:
+                db = torch.empty(pl.rows, dtype=torch.float32, device=x.device)
+            L.call("sp_linear_wgrad", ptr(x), x.stride(0), ptr(dy), dy.stride(0), ptr(dwsn), pl.cin_p, ptr(db), b, k, pl.rows, sp_dtype(dt), stream())
+        direct = pl.call.bank.direct_grads
+        return _zero1(x.device), (None if (direct or not need[1]) else db), None, None, None, None, None, None
+
+
+def reused_layer(module, x_saved, y_prev, pl_prev: PackedLayer):
+    """`module` applied to `x_saved` in the forward in flight, computed from its output `y_prev` of the earlier forward whose
+    PackedLayer is pl_prev (see _ReusedLayerFn)."""
+    pl = packed_layer(module, module.training, y_prev.dtype, y_prev.device)
+    ksize = getattr(module, "kernel_size", 1)
+    return _ReusedLayerFn.apply(pl.handle, module.bias, x_saved, y_prev, pl_prev, pl, ksize, module.weight_orig.shape[0])
+
+
 def linear_launch(x, w_ptr: int, kp: int, bias, res, y, b: int, k: int, n: int, act: int) -> None:
     """y[b][n] = act(x W^T + bias + res); large bf16 matrices go through the MFMA split-K path (fp32 scratch)."""
     scratch = None

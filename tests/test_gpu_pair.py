@@ -193,3 +193,64 @@ def test_pair_weight_gradient_equals_two_launches(case, dt):
         for got, ref in ((ba, ra), (bb, rb)):
             err = float((got - ref).abs().max() / ref.abs().max())
             assert err <= 2e-5, (case, err)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_second_generator_forward_reuses_the_feature_mappings(dtype, tol):
+    """Generator.map_mode (ModelWrapper: "stash" for the discriminator step's forward, "reuse" for the generator step's): the seven
+    masked-feature mappings of the second forward are derived from the first one's (same pyramid, masks and weight_orig; sigma has
+    moved on) by sp_rescale_bias, and their weight / bias gradients come from the stashed inputs.  Output, every gradient and the
+    (u, v) buffers must equal the plain computation (fp32: rounding of one multiply-add per element)."""
+    import semantic_pyramid_for_image_generation_amd as spm
+    from semantic_pyramid_for_image_generation_amd import models
+    ops.set_compute_dtype(dtype)
+    meta = {"cf": 4, "seed": 7}
+    Gsd, _, Vsd = gu.synth_states(meta)
+    images, labels, masks = gu.golden_batches(4, 3)[0]
+    images, labels, masks = images.cuda(), labels.cuda(), [m.cuda() for m in masks]
+    z = torch.randn(2, 4, 128, generator=torch.Generator().manual_seed(1)).cuda()
+    outs = []
+    for reuse in (False, True):
+        G, V = spm.Generator(channels_factor=4), spm.VGG16()
+        G.load_state_dict(Gsd); V.load_state_dict(Vsd)
+        G.cuda().train(); V.cuda().eval()
+        G._bank.direct_grads = True
+        with torch.no_grad():
+            feats = V(images)
+            if reuse:
+                G.map_mode = "stash"
+            G(input=z[0], features=feats, masks=masks, class_id=labels.float())
+        if reuse:
+            G.map_mode = "reuse"
+        img = G(input=z[1], features=feats, masks=masks, class_id=labels.float())
+        if reuse:
+            assert G._map_stash is None and G.map_mode is None
+        (img.float() ** 2).mean().backward()
+        G._bank.collect_extra()
+        torch.cuda.synchronize()
+        outs.append((img.detach().float().clone(), {n: p.grad.detach().float().clone() for n, p in G.named_parameters() if p.grad is not None},
+                     {n: b.detach().clone() for n, b in G.named_buffers()}))
+    (i0, g0, b0), (i1, g1, b1) = outs
+    # bf16: the two computations round differently (the reused mapping is rounded twice), and a 16-bit generator amplifies that like any
+    # other storage rounding - the worst of 786 K pixels moves as far as the bf16 mode moves against fp32 (tests/test_gpu_step.py)
+    assert float((i0 - i1).abs().max()) <= (tol if dtype == torch.float32 else 0.1)
+    assert float(((i0 - i1) ** 2).mean().sqrt()) <= (tol if dtype == torch.float32 else 1e-2)
+    assert set(g0) == set(g1)
+    if dtype == torch.float32:
+        dens = sorted(float(g0[n].abs().max()) for n in g0)
+        floor = 1e-2 * dens[len(dens) // 2]
+        for n in g0:
+            err = float((g0[n] - g1[n]).abs().max()) / max(float(g0[n].abs().max()), floor)
+            assert err <= 1e-3, (n, err)                 # 1e-7 differences of the mappings, amplified through the backward chain
+    else:
+        # 16-bit storage: parameters whose true gradient is zero (a bias in front of a BatchNorm) carry pure rounding noise - the
+        # gradient as a whole is what can be compared
+        a = torch.cat([g0[n].double().flatten() for n in sorted(g0)])
+        b = torch.cat([g1[n].double().flatten() for n in sorted(g0)])
+        cos = float((a * b).sum() / (a.norm() * b.norm()))
+        assert cos >= 0.99 and abs(float(a.norm() / b.norm()) - 1.0) <= 0.05, (cos, float(a.norm() / b.norm()))
+    for n in b0:
+        if n.endswith("weight_u") or n.endswith("weight_v"):
+            assert torch.equal(b0[n], b1[n]), n           # the power iterations see the weights only
+        elif b0[n].dtype.is_floating_point:                # BatchNorm running statistics follow the activations
+            assert torch.allclose(b0[n], b1[n], rtol=1e-5 if dtype == torch.float32 else 2e-2, atol=1e-7 if dtype == torch.float32 else 2e-3), n
