@@ -304,17 +304,36 @@ def kernel_probe(step_fn, peak, steps=6, step_ms=None):
             runs.append(ops.KERNEL_PROBE)
         finally:
             ops.KERNEL_PROBE = None
-    # what an EMPTY bracket measures (the two event packets themselves): subtracted from every interval - 290 launches x ~2 us of
-    # marker overhead were 5 % of the convolution time the first version of this probe reported
-    torch.cuda.synchronize()
-    gpu_blocker(5.0)
-    empties = []
-    for _ in range(64):
+    # what a bracket ADDS to the kernel it encloses: K small identical kernels timed (a) by ONE pair of events around all of them and
+    # (b) each inside its own bracket - the difference per kernel is the bracket's overhead with a kernel in it (an EMPTY bracket
+    # measures more, ~4.6 us: with a kernel in flight the command processor handles the closing marker in its shadow; calibrated this
+    # way the probe's convolution time agrees with rocprofv3's kernel time of the same box - profiles/README.md, round 4).  Subtracted
+    # from every interval: 260 launches x ~2 us were 4 % of the convolution time the first version of this probe reported.
+    from semantic_pyramid_for_image_generation_amd import _lib as _L
+    cal_x = torch.zeros(4096, dtype=torch.float32, device="cuda")
+    cal_y = torch.empty_like(cal_x)
+
+    def tiny():
+        _L.call("sp_act_fwd", ops.ptr(cal_x), ops.ptr(cal_y), cal_x.numel(), 0, _L.SP_F32, ops.stream())
+    K = 200
+    bracket_ms = None
+    for _ in range(3):
+        torch.cuda.synchronize()
+        gpu_blocker(10.0)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); e1.record()
-        empties.append((e0, e1))
-    torch.cuda.synchronize()
-    bracket_ms = min(a.elapsed_time(b) for a, b in empties)
+        e0.record()
+        for _ in range(K):
+            tiny()
+        e1.record()
+        pairs = []
+        for _ in range(K):
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record(); tiny(); a1.record()
+            pairs.append((a0, a1))
+        torch.cuda.synchronize()
+        est = (sum(a.elapsed_time(b) for a, b in pairs) - e0.elapsed_time(e1)) / K
+        bracket_ms = est if bracket_ms is None else min(bracket_ms, est)
+    bracket_ms = max(bracket_ms, 0.0)
     n = len(runs[0])
     same = all(len(r) == n and all(a[2:] == b[2:] for a, b in zip(r, runs[0])) for r in runs[1:])
     if same:
@@ -352,7 +371,7 @@ def kernel_probe(step_fn, peak, steps=6, step_ms=None):
     totals = {"tflops": round(tot_fl / max(tot_ms, 1e-9) / 1e9, 1), "ms_per_step": round(tot_ms, 3),
               "backward_tflops": round(bwd_fl / max(bwd_ms, 1e-9) / 1e9, 1),
               "method": "%d eager steps, each enqueued behind a %d+ ms stream blocker (host enqueue %.1f ms/step, never behind the GPU); "
-                        "per-launch minimum over the steps, minus the %.2f us an empty event bracket measures"
+                        "per-launch minimum over the steps, minus the %.2f us a bracket adds to the kernel inside it (calibrated on 200 small launches)"
                         % (len(runs), 60, sum(host_ms) / len(host_ms), bracket_ms * 1e3)}
     rejected = None
     floor, floor_src = nonconv_floor()
