@@ -185,6 +185,10 @@ int sp_wgrad_rows_launch_pair(const void* x, const void* dy, float* dw_a, float*
 int sp_wgrad1x1_launch(const void* x, const void* dy, float* dw, float* dbias, int n, int h, int w, int cin, int cout, int ld_dy,
                        float* ws, long ws_floats, hipStream_t s);
 long sp_wgrad1x1_workspace(int n, int h, int w, int cin, int cout, int ld_dy);
+int sp_wgrad1x1_launch_pair(const void* x, const void* dy, float* dw_a, float* dbias_a, float* dw_b, float* dbias_b, int n, int split, int h, int w,
+                            int cin, int cout, int ld_dy, float* ws, long ws_floats, hipStream_t s);
+int sp_wgrad3x3_cin8_launch_pair(const void* x, const void* dy, float* dw_a, float* dbias_a, float* dw_b, float* dbias_b, int n, int split, int h,
+                                 int w, int cout, int ld_dy, float* ws, long ws_floats, hipStream_t s);
 // ... and for the 3x3 layers with an 8-channel input
 int sp_wgrad3x3_cin8_launch(const void* x, const void* dy, float* dw, float* dbias, int n, int h, int w, int cout, int ld_dy, float* ws,
                             long ws_floats, hipStream_t s);

@@ -732,10 +732,19 @@ extern "C" int sp_conv2d_wgrad_accum_pair(const void* x, const void* dy, float* 
                                           sp_stream_t stream) {
     SP_CHECK_ARG(x && dy && dw_a && dw_b && split > 0 && split < n, "sp_conv2d_wgrad_accum_pair: bad args");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == SP_BF16 && ksize == 3 && sp_tune(SP_TUNE_WGRAD_ROWS, 1)) {
+    if (dtype == SP_BF16 && ksize == 3 && cin_p == 8 && !dy_pooled) {
+        // the padded RGB images: the streaming kernel, one launch over both groups + a reduce pass per group
+        const int rc = sp_wgrad3x3_cin8_launch_pair(x, dy, dw_a, dbias_a, dw_b, dbias_b, n, split, h, w_, cout, ld_dy, workspace, workspace_floats, s);
+        if (rc != 1) return rc;
+    }
+    if (dtype == SP_BF16 && ksize == 3 && cin_p != 8 && sp_tune(SP_TUNE_WGRAD_ROWS, 1)) {
         // one launch of the row walker over both groups where the group boundary falls between two of its blocks
         const int rc = sp_wgrad_rows_launch_pair(x, dy, dw_a, dbias_a, dw_b, dbias_b, n, split, h, w_, cin_p, cout, ld_dy, workspace, workspace_floats,
                                                  dy_pooled ? 1 : 0, s);
+        if (rc != 1) return rc;
+    }
+    if (dtype == SP_BF16 && ksize == 1 && !dy_pooled) {
+        const int rc = sp_wgrad1x1_launch_pair(x, dy, dw_a, dbias_a, dw_b, dbias_b, n, split, h, w_, cin_p, cout, ld_dy, workspace, workspace_floats, s);
         if (rc != 1) return rc;
     }
     // everything else: the two groups one after the other (contiguous image ranges)

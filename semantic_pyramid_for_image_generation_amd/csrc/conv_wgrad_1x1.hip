@@ -402,10 +402,39 @@ long sp_wgrad1x1_workspace(int n, int h, int w, int cin, int cout, int ld_dy) {
 }
 
 // SP_OK after launching, 1 if the layer is not covered (the caller falls back to the per-tap kernel)
+// Two reduce passes over the slab sub-ranges of the two groups of a two-group batch (sp_conv2d_wgrad_accum_pair): split k of the
+// streaming kernels covers the pixels [k, k + 1) * 64 * stages_per_split, so when the group boundary is a multiple of that every
+// slab belongs to one group.
+static void w1_reduce_groups(const W1Args& a, int nsplit, int kb, float* dw_a, float* dbias_a, float* dw_b, float* dbias_b, int cout, hipStream_t s) {
+    const long cols = a.n_dw / 4 + (a.bias_slabs != nullptr ? a.bias_ld / 4 : 0);
+    for (int g = 0; g < 2; ++g) {
+        const int k0 = g ? kb : 0, k1 = g ? nsplit : kb;
+        hipLaunchKernelGGL(wgrad1x1_reduce_kernel, dim3((unsigned)((cols + 15) / 16)), dim3(256), 0, s, a.slabs + (long)k0 * a.n_dw, k1 - k0, a.n_dw,
+                           g ? dw_b : dw_a, a.bias_slabs != nullptr ? a.bias_slabs + (long)k0 * a.bias_ld : nullptr, a.bias_ld, cout, g ? dbias_b : dbias_a);
+    }
+}
+
+static int w1_launch_impl(const void* x, const void* dy, float* dw, float* dbias, float* dw_b, float* dbias_b, long split_pixels, int n, int h, int w,
+                          int cin, int cout, int ld_dy, float* ws, long ws_floats, hipStream_t s);
+
 int sp_wgrad1x1_launch(const void* x, const void* dy, float* dw, float* dbias, int n, int h, int w, int cin, int cout, int ld_dy,
                        float* ws, long ws_floats, hipStream_t s) {
+    return w1_launch_impl(x, dy, dw, dbias, nullptr, nullptr, 0, n, h, w, cin, cout, ld_dy, ws, ws_floats, s);
+}
+
+// the two-group form: 1 unless the layer runs with slabs and the group boundary falls between two splits
+int sp_wgrad1x1_launch_pair(const void* x, const void* dy, float* dw_a, float* dbias_a, float* dw_b, float* dbias_b, int n, int split, int h, int w,
+                            int cin, int cout, int ld_dy, float* ws, long ws_floats, hipStream_t s) {
+    if (split <= 0 || split >= n || (dbias_a == nullptr) != (dbias_b == nullptr)) return 1;
+    return w1_launch_impl(x, dy, dw_a, dbias_a, dw_b, dbias_b, (long)split * h * w, n, h, w, cin, cout, ld_dy, ws, ws_floats, s);
+}
+
+static int w1_launch_impl(const void* x, const void* dy, float* dw, float* dbias, float* dw_b, float* dbias_b, long split_pixels, int n, int h, int w,
+                          int cin, int cout, int ld_dy, float* ws, long ws_floats, hipStream_t s) {
     const W1Plan p = w1_plan(n, h, w, cin, cout, ld_dy);
     if (!p.ok) return 1;
+    const long px_per_split = 64L * p.stages_per_split;
+    if (dw_b != nullptr && (p.nsplit <= 1 || split_pixels % px_per_split != 0)) return 1;
     W1Args a;
     a.x = reinterpret_cast<const bf16*>(x);
     a.dy = reinterpret_cast<const bf16*>(dy);
@@ -432,9 +461,14 @@ int sp_wgrad1x1_launch(const void* x, const void* dy, float* dw, float* dbias, i
         if (e != hipSuccess) { sp_set_error("hipFuncSetAttribute(LDS=%d) failed: %s", W1_LDS, hipGetErrorString(e)); return SP_ERR_LAUNCH; }
         attr_set = true;
     }
-    sp_note_route("wgrad1x1_stream + reduce");
+    sp_note_route(dw_b != nullptr ? "wgrad1x1_stream (two groups) + 2 x reduce" : "wgrad1x1_stream + reduce");
     hipLaunchKernelGGL(wgrad1x1_stream_kernel, dim3((unsigned)(p.tiles * (p.nsplit >= 8 ? ((p.nsplit + 7) / 8) * 8 : p.nsplit))), dim3(256), W1_LDS, s, a);
     SP_LAUNCH_CHECK();
+    if (dw_b != nullptr) {
+        w1_reduce_groups(a, p.nsplit, (int)(split_pixels / px_per_split), dw, dbias, dw_b, dbias_b, cout, s);
+        SP_LAUNCH_CHECK();
+        return SP_OK;
+    }
     if (p.nsplit > 1) {
         const long cols = a.n_dw / 4 + (a.bias_slabs != nullptr ? a.bias_ld / 4 : 0);
         hipLaunchKernelGGL(wgrad1x1_reduce_kernel, dim3((unsigned)((cols + 15) / 16)), dim3(256), 0, s, a.slabs, p.nsplit, a.n_dw, dw, a.bias_slabs,
@@ -469,10 +503,26 @@ long sp_wgrad3x3_cin8_workspace(int n, int h, int w, int cout, int ld_dy) {
     return (long)p.nsplit * ((long)cout * 72 + ((cout + 3) & ~3));
 }
 
+static int c8_launch_impl(const void* x, const void* dy, float* dw, float* dbias, float* dw_b, float* dbias_b, long split_pixels, int n, int h, int w,
+                          int cout, int ld_dy, float* ws, long ws_floats, hipStream_t s);
+
 int sp_wgrad3x3_cin8_launch(const void* x, const void* dy, float* dw, float* dbias, int n, int h, int w, int cout, int ld_dy, float* ws,
                             long ws_floats, hipStream_t s) {
+    return c8_launch_impl(x, dy, dw, dbias, nullptr, nullptr, 0, n, h, w, cout, ld_dy, ws, ws_floats, s);
+}
+
+int sp_wgrad3x3_cin8_launch_pair(const void* x, const void* dy, float* dw_a, float* dbias_a, float* dw_b, float* dbias_b, int n, int split, int h,
+                                 int w, int cout, int ld_dy, float* ws, long ws_floats, hipStream_t s) {
+    if (split <= 0 || split >= n || (dbias_a == nullptr) != (dbias_b == nullptr)) return 1;
+    return c8_launch_impl(x, dy, dw_a, dbias_a, dw_b, dbias_b, (long)split * h * w, n, h, w, cout, ld_dy, ws, ws_floats, s);
+}
+
+static int c8_launch_impl(const void* x, const void* dy, float* dw, float* dbias, float* dw_b, float* dbias_b, long split_pixels, int n, int h, int w,
+                          int cout, int ld_dy, float* ws, long ws_floats, hipStream_t s) {
     W1Plan p;
     if (!c8_plan(n, h, w, cout, ld_dy, p)) return 1;
+    const long px_per_split = 64L * p.stages_per_split;
+    if (dw_b != nullptr && (p.nsplit <= 1 || split_pixels % px_per_split != 0)) return 1;
     W1Args a;
     a.x = reinterpret_cast<const bf16*>(x);
     a.dy = reinterpret_cast<const bf16*>(dy);
@@ -502,10 +552,15 @@ int sp_wgrad3x3_cin8_launch(const void* x, const void* dy, float* dw, float* dbi
     int logw = 0, logh = 0;
     while ((1 << logw) < w) ++logw;
     while ((1 << logh) < h) ++logh;
-    sp_note_route("wgrad3x3_cin8_stream + reduce");
+    sp_note_route(dw_b != nullptr ? "wgrad3x3_cin8_stream (two groups) + 2 x reduce" : "wgrad3x3_cin8_stream + reduce");
     hipLaunchKernelGGL(wgrad3x3_cin8_stream_kernel, dim3((unsigned)(p.tiles * (p.nsplit >= 8 ? ((p.nsplit + 7) / 8) * 8 : p.nsplit))), dim3(256), C8_LDS, s, a,
                        h, w, logw, logh);
     SP_LAUNCH_CHECK();
+    if (dw_b != nullptr) {
+        w1_reduce_groups(a, p.nsplit, (int)(split_pixels / px_per_split), dw, dbias, dw_b, dbias_b, cout, s);
+        SP_LAUNCH_CHECK();
+        return SP_OK;
+    }
     if (p.nsplit > 1) {
         const long cols = a.n_dw / 4 + (a.bias_slabs != nullptr ? a.bias_ld / 4 : 0);
         hipLaunchKernelGGL(wgrad1x1_reduce_kernel, dim3((unsigned)((cols + 15) / 16)), dim3(256), 0, s, a.slabs, p.nsplit, a.n_dw, dw, a.bias_slabs,

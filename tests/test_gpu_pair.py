@@ -151,16 +151,20 @@ def test_fused_1x1_tail_matches_the_two_launches(dt):
 
 
 @pytest.mark.parametrize("case", [(8, 4, 64, 128, 32, 64, False), (40, 20, 128, 128, 64, 64, False), (8, 4, 64, 64, 64, 64, True),
-                                  (6, 2, 72, 40, 16, 32, False), (6, 3, 256, 256, 8, 8, False), (4, 2, 64, 128, 32, 32, False)])
+                                  (6, 2, 72, 40, 16, 32, False), (6, 3, 256, 256, 8, 8, False), (4, 2, 64, 128, 32, 32, False),
+                                  (40, 20, 64, 128, 64, 64, False, 1), (8, 4, 128, 256, 32, 32, False, 1), (6, 1, 64, 64, 16, 16, False, 1),
+                                  (40, 20, 8, 64, 128, 128, False, 3), (6, 2, 8, 64, 128, 128, False, 3), (5, 2, 8, 32, 24, 24, False, 3)])
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
 def test_pair_weight_gradient_equals_two_launches(case, dt):
     """sp_conv2d_wgrad_accum_pair: one launch of the row walker over both groups + a reduce pass per group (where the group boundary
     falls between two blocks), or the two groups one after the other - either way each group's (dW, dbias) must equal its own
     sp_conv2d_wgrad_accum call up to fp32 summation order.  Cases: the single-launch form (first three, the third with a pooled
-    gradient), a boundary that does not align, a small map (per-tap kernel), fp32 storage."""
+    gradient), a boundary that does not align, a small map (per-tap kernel), fp32 storage; 1x1 layers and the padded-RGB first layer
+    (streaming kernels: one launch over both groups when the boundary falls between two of their pixel splits)."""
     import ctypes
     from semantic_pyramid_for_image_generation_amd import _lib as L
-    n, split, cin, cout, h, w, pooled = case
+    n, split, cin, cout, h, w, pooled = case[:7]
+    ks = case[7] if len(case) > 7 else 3
     if dt == torch.float32 and pooled:
         pytest.skip("pooled gradients: 16-bit row walker only")
     torch.manual_seed(n * 100 + cin)
@@ -169,25 +173,25 @@ def test_pair_weight_gradient_equals_two_launches(case, dt):
     x = ops.nhwc_empty(n, cin, h, w, dt, "cuda").normal_()
     hd, wd = (h // 2, w // 2) if pooled else (h, w)
     dy = ops.nhwc_empty(n, cp, hd, wd, dt, "cuda").normal_()
-    ndw = cout * 9 * cin
+    ndw = cout * ks * ks * cin
     spd = ops.sp_dtype(dt)
 
     def single(lo, hi):
         buf = torch.zeros(ndw + cout + 8, dtype=torch.float32, device="cuda")
-        wsf = ops.wgrad_workspace_floats(hi - lo, h, w, cin, cout, 3, dt)
+        wsf = ops.wgrad_workspace_floats(hi - lo, h, w, cin, cout, ks, dt)
         ws = torch.empty(max(wsf, 1), dtype=torch.float32, device="cuda")
         L.call("sp_conv2d_wgrad_accum_pooled" if pooled else "sp_conv2d_wgrad_accum", ops.ptr(x.narrow(0, lo, hi - lo)),
                ops.ptr(dy.narrow(0, lo, hi - lo)), ops.ptr(buf), ctypes.c_void_p(buf.data_ptr() + 4 * (ndw + 4)), ops.ptr(ws) if wsf else None,
-               wsf, hi - lo, h, w, cin, cout, cp, 3, spd, ops.stream())
+               wsf, hi - lo, h, w, cin, cout, cp, ks, spd, ops.stream())
         return buf
     ra, rb = single(0, split), single(split, n)
     for _ in range(2):
         ba = torch.zeros(ndw + cout + 8, dtype=torch.float32, device="cuda")
         bb = torch.zeros(ndw + cout + 8, dtype=torch.float32, device="cuda")
-        wsf = ops.wgrad_workspace_floats(n, h, w, cin, cout, 3, dt)
+        wsf = ops.wgrad_workspace_floats(n, h, w, cin, cout, ks, dt)
         ws = torch.empty(max(wsf, 1), dtype=torch.float32, device="cuda")
         L.call("sp_conv2d_wgrad_accum_pair", ops.ptr(x), ops.ptr(dy), ops.ptr(ba), ctypes.c_void_p(ba.data_ptr() + 4 * (ndw + 4)), ops.ptr(bb),
-               ctypes.c_void_p(bb.data_ptr() + 4 * (ndw + 4)), ops.ptr(ws) if wsf else None, wsf, n, split, h, w, cin, cout, cp, 3,
+               ctypes.c_void_p(bb.data_ptr() + 4 * (ndw + 4)), ops.ptr(ws) if wsf else None, wsf, n, split, h, w, cin, cout, cp, ks,
                1 if pooled else 0, spd, ops.stream())
         torch.cuda.synchronize()
         for got, ref in ((ba, ra), (bb, rb)):
