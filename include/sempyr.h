@@ -437,6 +437,24 @@ int sp_div_loss_fwd(const void* img, int64_t half_elems, const float* z, int64_t
                     float* out2, int32_t dtype, sp_stream_t stream);
 int sp_div_loss_bwd(const void* img, int64_t half_elems, const float* fwd_out2, const float* gout, void* dimg,
                     int32_t dtype, sp_stream_t stream);
+/* One-launch forms of the loss plumbing (a small launch costs ~5 us of queue time whatever it computes; the three generator losses
+ * used to take 36 launches).  `weight`: the factor the caller multiplies the loss by (model_wrapper.py:183-186's w_rec / w_div) - the
+ * value written is weight * loss and the backward forms scale by it, so no elementwise launch is needed around them.  `acc`: fp64
+ * accumulators (1 for the reconstruction loss, 2 for the diversity loss) that are ZERO on entry and left zero: allocate and clear
+ * once, pass to every call of one stream.
+ * sp_rec_loss_fwd_levels / _bwd_levels: all pyramid levels (<= 8) of lossfunction.py:31-68 in one launch each; a level with
+ * h = w_ = 1 is a 2-D (fully connected) level with c features per row.  sp_sqerr_loss_fwd itself runs as one block up to 2^18 elements. */
+typedef struct sp_rec_level {
+    const void* real; const void* fake; const float* mask;
+    void* dfake;                                   /* backward only */
+    int32_t ld_real, ld_fake, ld_dfake, n, h, w_, c, reserved_;
+} sp_rec_level;
+int sp_rec_loss_fwd_levels(const sp_rec_level* levels, int32_t n_levels, double* acc, float* loss, float weight,
+                           int32_t dtype, sp_stream_t stream);
+int sp_rec_loss_bwd_levels(const sp_rec_level* levels, int32_t n_levels, const float* gout, float weight,
+                           int32_t dtype, sp_stream_t stream);
+int sp_div_loss_fwd_w(const void* img, int64_t half_elems, const float* z, int64_t half_z, double* acc,
+                      float* out2, float weight, int32_t dtype, sp_stream_t stream);
 
 /* fp8 (OCP e4m3) helpers of the SP_F8 convolution path (BASELINE.json config 5).
  * sp_quantize_fp8: q[i] = e4m3(sat(x[i] * inv_scale[0])) for a bf16 / fp32 tensor of `numel` elements (numel % 16 == 0);

@@ -61,6 +61,12 @@ class SpSnBwdLayer(ctypes.Structure):
                 ("bias_off", ctypes.c_int32)]
 
 
+class SpRecLevel(ctypes.Structure):
+    _fields_ = [("real", ctypes.c_void_p), ("fake", ctypes.c_void_p), ("mask", ctypes.c_void_p), ("dfake", ctypes.c_void_p),
+                ("ld_real", ctypes.c_int32), ("ld_fake", ctypes.c_int32), ("ld_dfake", ctypes.c_int32), ("n", ctypes.c_int32),
+                ("h", ctypes.c_int32), ("w_", ctypes.c_int32), ("c", ctypes.c_int32), ("reserved_", ctypes.c_int32)]
+
+
 _CTYPE = {"int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "double": ctypes.c_double, "int": ctypes.c_int,
           "sp_stream_t": ctypes.c_void_p, "uint64_t": ctypes.c_uint64}
 

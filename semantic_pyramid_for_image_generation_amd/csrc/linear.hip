@@ -107,9 +107,12 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const T* __restrict__
 // LM_KS = k per block: 1024 for very long rows (25 splits of the 25088-wide classifier input), 512 otherwise (4096-wide
 // layers: 8 splits x 32 row tiles = 256 blocks instead of 128)
 
+// the layer's epilogue, for launches whose single K-split finishes the layer itself (y != nullptr: no slab, no finalize pass)
+struct LinTail { const float* bias; const bf16* res; bf16* y; int ldy, act; };
+
 template <int LM_KS>
 __global__ __launch_bounds__(256) void linear_mfma_kernel(const bf16* __restrict__ x, int ldx, const bf16* __restrict__ wp, int kp,
-                                                          float* __restrict__ acc_out, int B, int K, int N) {
+                                                          float* __restrict__ acc_out, int B, int K, int N, LinTail tail) {
     constexpr int LM_PITCH = LM_KS * 2 + 16;
     extern __shared__ __attribute__((aligned(16))) char xs_raw[];     // [32][LM_PITCH bytes]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -189,7 +192,15 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const bf16* __restrict
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = n0 + i * 16 + (lane >> 4) * 4 + r;
-                if (n < N) acc_out[((long)blockIdx.y * B + b) * N + n] = acc[i][j][r];    // this K-split's slab [B][N]
+                if (n >= N) continue;
+                if (tail.y == nullptr) {
+                    acc_out[((long)blockIdx.y * B + b) * N + n] = acc[i][j][r];            // this K-split's slab [B][N]
+                } else {                                                                     // the only K-split: the layer's epilogue
+                    const long off = (long)b * tail.ldy + n;
+                    float v = acc[i][j][r] + (tail.bias ? tail.bias[n] : 0.f);
+                    if (tail.res) v += Elem<bf16>::ld(tail.res + off);
+                    Elem<bf16>::st(tail.y + off, apply_act(v, tail.act));
+                }
             }
         }
 }
@@ -213,15 +224,19 @@ __global__ void linear_finalize_kernel(const float* __restrict__ acc, int nsplit
 
 // K per block: 1024 for the 25088-wide classifier input, 512 for the 2048 / 4096-wide layers, 128 for the small ones (a
 // 768 -> 128 layer then runs on 6 blocks + the finalize pass instead of 16 single-wave dot-product loops: 25 -> ~8 us)
-static inline int linear_ks(int kp) { return kp > 8192 ? 1024 : (kp >= 2048 ? 512 : 128); }
+// Rows of up to 1024 values take ONE split (K per block = the smallest of 128 / 512 / 1024 that covers the row): the block applies
+// bias / residual / activation from its registers and the finalize launch - ~5 us of queue time, as much as the layer itself - is gone
+// (the latent / linear-block 128 -> 128 layers, D's 768 -> 128, the 365 -> 128 class mapping and their input gradients).
+static inline int linear_ks(int kp) { return kp > 8192 ? 1024 : (kp >= 2048 ? 512 : (kp > 1024 ? 128 : (kp > 512 ? 1024 : (kp > 128 ? 512 : 128)))); }
 static inline bool linear_use_mfma(int dtype, int batch, int k, int n) { return dtype == SP_BF16 && batch <= 32 && (long)k * n >= (1L << 12); }
 
 template <int KS>
-static void launch_linear_mfma(dim3 grid, hipStream_t s, const bf16* x, int ldx, const bf16* w, int kp, float* scratch, int batch, int k, int n) {
+static void launch_linear_mfma(dim3 grid, hipStream_t s, const bf16* x, int ldx, const bf16* w, int kp, float* scratch, int batch, int k, int n,
+                               const LinTail& tail) {
     static bool a = false;
     const int lds = 32 * (KS * 2 + 16);
     if (!a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_mfma_kernel<KS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); a = true; }
-    hipLaunchKernelGGL(linear_mfma_kernel<KS>, grid, dim3(256), lds, s, x, ldx, w, kp, scratch, batch, k, n);
+    hipLaunchKernelGGL(linear_mfma_kernel<KS>, grid, dim3(256), lds, s, x, ldx, w, kp, scratch, batch, k, n, tail);
 }
 
 extern "C" int sp_linear_fwd(const void* x, int32_t ldx, const void* w_packed, int32_t kp, const float* bias,
@@ -278,10 +293,12 @@ extern "C" int sp_linear_fwd_ws(const void* x, int32_t ldx, const void* w_packed
     const int ks = linear_ks(kp);
     const int nsplit = sp_div_up(kp, ks);
     dim3 grid(sp_div_up(n, 128), nsplit);
-    if (ks == 1024) launch_linear_mfma<1024>(grid, s, (const bf16*)x, ldx, (const bf16*)w_packed, kp, scratch, batch, k, n);
-    else if (ks == 512) launch_linear_mfma<512>(grid, s, (const bf16*)x, ldx, (const bf16*)w_packed, kp, scratch, batch, k, n);
-    else launch_linear_mfma<128>(grid, s, (const bf16*)x, ldx, (const bf16*)w_packed, kp, scratch, batch, k, n);
+    const LinTail tail{bias, (const bf16*)res, nsplit == 1 ? (bf16*)y : nullptr, ldy, act};
+    if (ks == 1024) launch_linear_mfma<1024>(grid, s, (const bf16*)x, ldx, (const bf16*)w_packed, kp, scratch, batch, k, n, tail);
+    else if (ks == 512) launch_linear_mfma<512>(grid, s, (const bf16*)x, ldx, (const bf16*)w_packed, kp, scratch, batch, k, n, tail);
+    else launch_linear_mfma<128>(grid, s, (const bf16*)x, ldx, (const bf16*)w_packed, kp, scratch, batch, k, n, tail);
     SP_LAUNCH_CHECK();
+    if (nsplit == 1) return SP_OK;
     int fb = sp_div_up((long)batch * n, 256);
     if (fb > 1024) fb = 1024;
     hipLaunchKernelGGL(linear_finalize_kernel<bf16>, dim3(fb), dim3(256), 0, s, scratch, nsplit, bias, (const bf16*)res, (bf16*)y, ldy, batch, n, act);

@@ -101,6 +101,41 @@ __global__ void sqerr_fwd_kernel(const float* __restrict__ p, long n, float targ
     const float tot = block_sum_256(part, red);
     if (threadIdx.x == 0) atomicAdd(acc, (double)tot * 0.5 / (double)n);
 }
+// small inputs (the discriminator's (B, B, F) prediction): ONE block, fixed summation order, no accumulator / second launch.
+// Four independent 16-byte loads per thread and trip (a single dependent load per trip made this 14 us for 51 200 values).
+__global__ __launch_bounds__(1024) void sqerr_fwd_small_kernel(const float* __restrict__ p, int n, float target, float* __restrict__ loss) {
+    __shared__ double red[16];
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
+    const int n4 = ((reinterpret_cast<uintptr_t>(p) & 15) == 0) ? n / 4 : 0;
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+    int i = threadIdx.x;
+    for (; i + 3 * 1024 < n4; i += 4 * 1024) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = p4[i + u * 1024];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float a = v[u].x - target, b = v[u].y - target, c = v[u].z - target, d = v[u].w - target;
+            part[u] += (a * a + b * b) + (c * c + d * d);
+        }
+    }
+    for (; i < n4; i += 1024) {
+        const float4 v = p4[i];
+        const float a = v.x - target, b = v.y - target, c = v.z - target, d = v.w - target;
+        part[0] += (a * a + b * b) + (c * c + d * d);
+    }
+    for (int j = n4 * 4 + threadIdx.x; j < n; j += 1024) { const float d = p[j] - target; part[1] += d * d; }
+    double t = ((double)part[0] + (double)part[1]) + ((double)part[2] + (double)part[3]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int k = 0; k < 16; ++k) tot += red[k];
+        loss[0] = (float)(tot * 0.5 / (double)n);
+    }
+}
 __global__ void sqerr_bwd_kernel(const float* __restrict__ p, long n, float target, const float* __restrict__ gout, float* __restrict__ dp) {
     const float g = gout[0] / (float)n;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dp[i] = g * (p[i] - target);
@@ -120,14 +155,14 @@ __device__ __forceinline__ void max4(const T* b, long W, int C, float o[4]) {
     Elem<T>::ld4(b + W * C + C, t); for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r], t[r]);
 }
 
+// this thread's share of sum |maxpool(real) - maxpool(fake)| * maxpool(mask) when block `blk` of `nblk` walks the level
 template <typename T>
-__global__ void rec4d_fwd_kernel(const T* __restrict__ real, const T* __restrict__ fake, const float* __restrict__ mask, int N, int H,
-                                 int W, int C, double* __restrict__ acc) {
-    __shared__ float red[4];
+__device__ __forceinline__ float rec4d_fwd_part(const T* __restrict__ real, const T* __restrict__ fake, const float* __restrict__ mask, int N,
+                                                int H, int W, int C, int blk, int nblk) {
     const int OH = H / 2, OW = W / 2, vpp = C / 4;
     const long total = (long)N * OH * OW * vpp;
     float part = 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    for (long i = (long)blk * 256 + threadIdx.x; i < total; i += (long)nblk * 256) {
         const int c = (int)(i % vpp) * 4;
         const long pp = i / vpp;
         const int ow = (int)(pp % OW);
@@ -141,18 +176,25 @@ __global__ void rec4d_fwd_kernel(const T* __restrict__ real, const T* __restrict
         max4(fake + pix * C + c, (long)W, C, f);
         for (int k = 0; k < 4; ++k) part += fabsf((r[k] - f[k]) * m);
     }
+    return part;
+}
+template <typename T>
+__global__ void rec4d_fwd_kernel(const T* __restrict__ real, const T* __restrict__ fake, const float* __restrict__ mask, int N, int H,
+                                 int W, int C, double* __restrict__ acc) {
+    __shared__ float red[4];
+    const float part = rec4d_fwd_part<T>(real, fake, mask, N, H, W, C, (int)blockIdx.x, (int)gridDim.x);
     const float tot = block_sum_256(part, red);
-    if (threadIdx.x == 0) atomicAdd(acc, (double)tot / (double)((long)N * OH * OW * C));
+    if (threadIdx.x == 0) atomicAdd(acc, (double)tot / (double)((long)N * (H / 2) * (W / 2) * C));
 }
 
 // dfake: -g * sign((r - f) * m) * m / count at the first maximum of each fake window, 0 elsewhere
 template <typename T>
-__global__ void rec4d_bwd_kernel(const T* __restrict__ real, const T* __restrict__ fake, const float* __restrict__ mask,
-                                 const float* __restrict__ gout, T* __restrict__ dfake, int N, int H, int W, int C) {
+__device__ __forceinline__ void rec4d_bwd_part(const T* __restrict__ real, const T* __restrict__ fake, const float* __restrict__ mask,
+                                               float gup, T* __restrict__ dfake, int N, int H, int W, int C, int blk, int nblk) {
     const int OH = H / 2, OW = W / 2, vpp = C / 4;
     const long total = (long)N * OH * OW * vpp;
-    const float g = gout[0] / (float)((long)N * OH * OW * C);
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const float g = gup / (float)((long)N * OH * OW * C);
+    for (long i = (long)blk * 256 + threadIdx.x; i < total; i += (long)nblk * 256) {
         const int c = (int)(i % vpp) * 4;
         const long pp = i / vpp;
         const int ow = (int)(pp % OW);
@@ -176,31 +218,43 @@ __global__ void rec4d_bwd_kernel(const T* __restrict__ real, const T* __restrict
         for (int k = 0; k < 4; ++k) Elem<T>::st4(dfake + pix * C + c + offs[k], o[k]);
     }
 }
+template <typename T>
+__global__ void rec4d_bwd_kernel(const T* __restrict__ real, const T* __restrict__ fake, const float* __restrict__ mask,
+                                 const float* __restrict__ gout, T* __restrict__ dfake, int N, int H, int W, int C) {
+    rec4d_bwd_part<T>(real, fake, mask, gout[0], dfake, N, H, W, C, (int)blockIdx.x, (int)gridDim.x);
+}
 
 // ---------------- semantic reconstruction, 2-D level (MaxPool1d(2) over pairs) ----------------
 template <typename T>
-__global__ void rec2d_fwd_kernel(const T* __restrict__ real, int ldr, const T* __restrict__ fake, int ldf, const float* __restrict__ mask,
-                                 int B, int K, double* __restrict__ acc) {
-    __shared__ float red[4];
+__device__ __forceinline__ float rec2d_fwd_part(const T* __restrict__ real, int ldr, const T* __restrict__ fake, int ldf,
+                                                const float* __restrict__ mask, int B, int K, int blk, int nblk) {
     const int KH = K / 2;
     float part = 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)B * KH; i += (long)gridDim.x * 256) {
+    for (long i = (long)blk * 256 + threadIdx.x; i < (long)B * KH; i += (long)nblk * 256) {
         const int b = (int)(i / KH), k = (int)(i % KH) * 2;
         const float m = fmaxf(mask[(long)b * K + k], mask[(long)b * K + k + 1]);
         const float r = fmaxf(Elem<T>::ld(real + (long)b * ldr + k), Elem<T>::ld(real + (long)b * ldr + k + 1));
         const float f = fmaxf(Elem<T>::ld(fake + (long)b * ldf + k), Elem<T>::ld(fake + (long)b * ldf + k + 1));
         part += fabsf((r - f) * m);
     }
+    return part;
+}
+template <typename T>
+__global__ void rec2d_fwd_kernel(const T* __restrict__ real, int ldr, const T* __restrict__ fake, int ldf, const float* __restrict__ mask,
+                                 int B, int K, double* __restrict__ acc) {
+    __shared__ float red[4];
+    const float part = rec2d_fwd_part<T>(real, ldr, fake, ldf, mask, B, K, (int)blockIdx.x, (int)gridDim.x);
     const float tot = block_sum_256(part, red);
-    if (threadIdx.x == 0) atomicAdd(acc, (double)tot / (double)((long)B * KH));
+    if (threadIdx.x == 0) atomicAdd(acc, (double)tot / (double)((long)B * (K / 2)));
 }
 
 template <typename T>
-__global__ void rec2d_bwd_kernel(const T* __restrict__ real, int ldr, const T* __restrict__ fake, int ldf, const float* __restrict__ mask,
-                                 const float* __restrict__ gout, T* __restrict__ dfake, int ldd, int B, int K) {
+__device__ __forceinline__ void rec2d_bwd_part(const T* __restrict__ real, int ldr, const T* __restrict__ fake, int ldf,
+                                               const float* __restrict__ mask, float gup, T* __restrict__ dfake, int ldd, int B, int K, int blk,
+                                               int nblk) {
     const int KH = K / 2;
-    const float g = gout[0] / (float)((long)B * KH);
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)B * ((K + 1) / 2); i += (long)gridDim.x * 256) {
+    const float g = gup / (float)((long)B * KH);
+    for (long i = (long)blk * 256 + threadIdx.x; i < (long)B * ((K + 1) / 2); i += (long)nblk * 256) {
         const int b = (int)(i / ((K + 1) / 2)), k = (int)(i % ((K + 1) / 2)) * 2;
         if (k + 1 >= K) { Elem<T>::st(dfake + (long)b * ldd + k, 0.f); continue; }     // odd tail is dropped by the pool
         const float m = fmaxf(mask[(long)b * K + k], mask[(long)b * K + k + 1]);
@@ -212,6 +266,51 @@ __global__ void rec2d_bwd_kernel(const T* __restrict__ real, int ldr, const T* _
         Elem<T>::st(dfake + (long)b * ldd + k + best, -g * s * m);
         Elem<T>::st(dfake + (long)b * ldd + k + 1 - best, 0.f);
     }
+}
+template <typename T>
+__global__ void rec2d_bwd_kernel(const T* __restrict__ real, int ldr, const T* __restrict__ fake, int ldf, const float* __restrict__ mask,
+                                 const float* __restrict__ gout, T* __restrict__ dfake, int ldd, int B, int K) {
+    rec2d_bwd_part<T>(real, ldr, fake, ldf, mask, gout[0], dfake, ldd, B, K, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// ---------------- all pyramid levels of the semantic reconstruction loss in one launch ----------------
+// The level descriptors travel as a kernel argument; block b serves the level whose block range holds it.
+constexpr int REC_MAX_LEVELS = 8;
+struct RecLevels { sp_rec_level lv[REC_MAX_LEVELS]; int first_block[REC_MAX_LEVELS + 1]; int n; };
+
+template <typename T>
+__global__ void rec_fwd_levels_kernel(RecLevels a, double* __restrict__ acc) {
+    __shared__ float red[4];
+    int l = 0;
+    while (l + 1 < a.n && (int)blockIdx.x >= a.first_block[l + 1]) ++l;
+    const int blk = (int)blockIdx.x - a.first_block[l], nblk = a.first_block[l + 1] - a.first_block[l];
+    const sp_rec_level& L = a.lv[l];
+    float part;
+    double count;
+    if (L.h > 1 || L.w_ > 1) {
+        part = rec4d_fwd_part<T>((const T*)L.real, (const T*)L.fake, L.mask, L.n, L.h, L.w_, L.c, blk, nblk);
+        count = (double)((long)L.n * (L.h / 2) * (L.w_ / 2) * L.c);
+    } else {
+        part = rec2d_fwd_part<T>((const T*)L.real, L.ld_real, (const T*)L.fake, L.ld_fake, L.mask, L.n, L.c, blk, nblk);
+        count = (double)((long)L.n * (L.c / 2));
+    }
+    const float tot = block_sum_256(part, red);
+    if (threadIdx.x == 0) atomicAdd(acc, (double)tot / count);
+}
+template <typename T>
+__global__ void rec_bwd_levels_kernel(RecLevels a, const float* __restrict__ gout, float weight) {
+    int l = 0;
+    while (l + 1 < a.n && (int)blockIdx.x >= a.first_block[l + 1]) ++l;
+    const int blk = (int)blockIdx.x - a.first_block[l], nblk = a.first_block[l + 1] - a.first_block[l];
+    const sp_rec_level& L = a.lv[l];
+    const float gup = gout[0] * weight;
+    if (L.h > 1 || L.w_ > 1) rec4d_bwd_part<T>((const T*)L.real, (const T*)L.fake, L.mask, gup, (T*)L.dfake, L.n, L.h, L.w_, L.c, blk, nblk);
+    else rec2d_bwd_part<T>((const T*)L.real, L.ld_real, (const T*)L.fake, L.ld_fake, L.mask, gup, (T*)L.dfake, L.ld_dfake, L.n, L.c, blk, nblk);
+}
+// out[i] = weight * (float)acc[i]; the accumulators go back to zero (the contract of the one-launch forms: zero on entry and exit)
+__global__ void loss_finalize_kernel(double* __restrict__ acc, float* __restrict__ out, int n, float weight) {
+    const int i = threadIdx.x;
+    if (i < n) { out[i] = (float)acc[i] * weight; acc[i] = 0.0; }
 }
 
 // ---------------- diversity loss ----------------
@@ -228,10 +327,11 @@ __global__ void div_fwd_kernel(const T* __restrict__ img, long half_elems, const
     const float tz = block_sum_256(pz, red);
     if (threadIdx.x == 0) { atomicAdd(acc, (double)ti); if (blockIdx.x == 0) atomicAdd(acc + 1, (double)tz); }
 }
-__global__ void div_finalize_kernel(const double* __restrict__ acc, long half_elems, long half_z, float* __restrict__ out) {
+__global__ void div_finalize_kernel(double* __restrict__ acc, long half_elems, long half_z, float* __restrict__ out, float weight, int rezero) {
     const double den = acc[0] / (double)half_elems, num = acc[1] / (double)half_z;
-    out[0] = (float)(num / (den + 1e-8));
-    out[1] = (float)(-num / ((den + 1e-8) * (den + 1e-8)) / (double)half_elems);     // d loss / d |img1-img2| element
+    out[0] = (float)(num / (den + 1e-8)) * weight;
+    out[1] = (float)(-num / ((den + 1e-8) * (den + 1e-8)) / (double)half_elems) * weight;     // d loss / d |img1-img2| element
+    if (rezero) { acc[0] = 0.0; acc[1] = 0.0; }
 }
 template <typename T>
 __global__ void div_bwd_kernel(const T* __restrict__ img, long half_elems, const float* __restrict__ fwd_out, const float* __restrict__ gout,
@@ -279,6 +379,11 @@ extern "C" int sp_sqerr_loss_fwd(const float* p, int64_t numel, float target, do
                                  sp_stream_t stream) {
     SP_CHECK_ARG(p && acc_tmp && loss && numel > 0, "sp_sqerr_loss_fwd: bad args");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (numel <= (1 << 18)) {
+        hipLaunchKernelGGL(sqerr_fwd_small_kernel, dim3(1), dim3(1024), 0, s, p, (int)numel, target, loss);
+        SP_LAUNCH_CHECK();
+        return SP_OK;
+    }
     if (hipMemsetAsync(acc_tmp, 0, sizeof(double), s) != hipSuccess) { sp_set_error("sp_sqerr_loss_fwd: memset failed"); return SP_ERR_LAUNCH; }
     hipLaunchKernelGGL(sqerr_fwd_kernel, dim3(red_grid(numel)), dim3(256), 0, s, p, (long)numel, target, acc_tmp);
     hipLaunchKernelGGL(dbl_to_f32_kernel, dim3(1), dim3(256), 0, s, acc_tmp, loss, 1);
@@ -349,7 +454,67 @@ extern "C" int sp_div_loss_fwd(const void* img, int64_t half_elems, const float*
     const int g = red_grid(half_elems);
     if (dtype == SP_F32) hipLaunchKernelGGL(div_fwd_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)img, (long)half_elems, z, (long)half_z, acc_tmp);
     else hipLaunchKernelGGL(div_fwd_kernel<bf16>, dim3(g), dim3(256), 0, s, (const bf16*)img, (long)half_elems, z, (long)half_z, acc_tmp);
-    hipLaunchKernelGGL(div_finalize_kernel, dim3(1), dim3(1), 0, s, acc_tmp, (long)half_elems, (long)half_z, out2);
+    hipLaunchKernelGGL(div_finalize_kernel, dim3(1), dim3(1), 0, s, acc_tmp, (long)half_elems, (long)half_z, out2, 1.0f, 0);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_div_loss_fwd_w(const void* img, int64_t half_elems, const float* z, int64_t half_z, double* acc,
+                                 float* out2, float weight, int32_t dtype, sp_stream_t stream) {
+    SP_CHECK_ARG(img && z && acc && out2 && half_elems > 0 && half_z > 0, "sp_div_loss_fwd_w: bad args");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int g = red_grid(half_elems);
+    if (dtype == SP_F32) hipLaunchKernelGGL(div_fwd_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)img, (long)half_elems, z, (long)half_z, acc);
+    else hipLaunchKernelGGL(div_fwd_kernel<bf16>, dim3(g), dim3(256), 0, s, (const bf16*)img, (long)half_elems, z, (long)half_z, acc);
+    hipLaunchKernelGGL(div_finalize_kernel, dim3(1), dim3(1), 0, s, acc, (long)half_elems, (long)half_z, out2, weight, 1);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+static int rec_levels_plan(const sp_rec_level* levels, int n_levels, bool bwd, RecLevels& a, const char* who) {
+    SP_CHECK_ARG(levels && n_levels > 0 && n_levels <= REC_MAX_LEVELS, "%s: 1..%d levels", who, REC_MAX_LEVELS);
+    a.n = n_levels;
+    a.first_block[0] = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        const sp_rec_level& L = levels[l];
+        SP_CHECK_ARG(L.real && L.fake && L.mask && L.n > 0 && L.c > 0 && (!bwd || L.dfake), "%s: level %d: bad args", who, l);
+        long items;
+        if (L.h > 1 || L.w_ > 1) {
+            SP_CHECK_ARG(L.c % 4 == 0 && L.h % 2 == 0 && L.w_ % 2 == 0 && L.ld_real == L.c && L.ld_fake == L.c && (!bwd || L.ld_dfake == L.c),
+                         "%s: level %d: a 4-D level needs even H, W and dense C %% 4 == 0", who, l);
+            items = (long)L.n * (L.h / 2) * (L.w_ / 2) * (L.c / 4);
+        } else {
+            items = (long)L.n * (bwd ? (L.c + 1) / 2 : L.c / 2);
+        }
+        a.lv[l] = L;
+        a.first_block[l + 1] = a.first_block[l] + (bwd ? ew_grid(items) : red_grid(items));
+    }
+    return SP_OK;
+}
+
+extern "C" int sp_rec_loss_fwd_levels(const sp_rec_level* levels, int32_t n_levels, double* acc, float* loss, float weight,
+                                      int32_t dtype, sp_stream_t stream) {
+    RecLevels a;
+    const int rc = rec_levels_plan(levels, n_levels, false, a, "sp_rec_loss_fwd_levels");
+    if (rc != SP_OK) return rc;
+    SP_CHECK_ARG(acc && loss, "sp_rec_loss_fwd_levels: null pointer");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == SP_F32) hipLaunchKernelGGL(rec_fwd_levels_kernel<float>, dim3(a.first_block[a.n]), dim3(256), 0, s, a, acc);
+    else hipLaunchKernelGGL(rec_fwd_levels_kernel<bf16>, dim3(a.first_block[a.n]), dim3(256), 0, s, a, acc);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, acc, loss, 1, weight);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_rec_loss_bwd_levels(const sp_rec_level* levels, int32_t n_levels, const float* gout, float weight,
+                                      int32_t dtype, sp_stream_t stream) {
+    RecLevels a;
+    const int rc = rec_levels_plan(levels, n_levels, true, a, "sp_rec_loss_bwd_levels");
+    if (rc != SP_OK) return rc;
+    SP_CHECK_ARG(gout, "sp_rec_loss_bwd_levels: null pointer");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == SP_F32) hipLaunchKernelGGL(rec_bwd_levels_kernel<float>, dim3(a.first_block[a.n]), dim3(256), 0, s, a, gout, weight);
+    else hipLaunchKernelGGL(rec_bwd_levels_kernel<bf16>, dim3(a.first_block[a.n]), dim3(256), 0, s, a, gout, weight);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }

@@ -20,9 +20,11 @@ class SemanticReconstructionLoss(nn.Module):
         return '{}, maxpool kernel size{}'.format(self.__class__.__name__, self.max_pooling_1d.kernel_size)
 
     def forward(self, features_real: List[torch.Tensor], features_fake: List[torch.Tensor],
-                masks: List[torch.Tensor]) -> torch.Tensor:
+                masks: List[torch.Tensor], weight: float = 1.0) -> torch.Tensor:
+        """`weight` (not in the reference's signature): the factor model_wrapper.py:186 multiplies the loss by, folded into the
+        kernels - the value returned is weight * loss."""
         assert len(features_real) == len(features_fake) == len(masks)
-        return ops.semantic_reconstruction_loss(features_real, features_fake, masks)
+        return ops.semantic_reconstruction_loss(features_real, features_fake, masks, weight)
 
 
 class DiversityLoss(nn.Module):
@@ -35,9 +37,10 @@ class DiversityLoss(nn.Module):
     def __repr__(self):
         return self.__class__.__name__
 
-    def forward(self, images_fake: torch.Tensor, latent_inputs: torch.Tensor) -> torch.Tensor:
+    def forward(self, images_fake: torch.Tensor, latent_inputs: torch.Tensor, weight: float = 1.0) -> torch.Tensor:
+        """`weight` (not in the reference's signature): model_wrapper.py:184's factor, folded into the kernels."""
         assert images_fake.shape[0] > 1
-        return ops.diversity_loss(images_fake, latent_inputs)
+        return ops.diversity_loss(images_fake, latent_inputs, weight)
 
 
 class LSGANGeneratorLoss(nn.Module):

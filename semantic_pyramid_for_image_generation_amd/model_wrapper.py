@@ -177,7 +177,8 @@ class ModelWrapper(object):
             prediction_fake = D(images_fake, labels)
         loss_d_real, loss_d_fake = self.discriminator_loss(prediction_real, prediction_fake)
         self._arm_reducer("d")
-        (loss_d_real + loss_d_fake).backward(gradient=ops.loss_scale_seed(images_real.device))
+        # d(real + fake): one seed per loss instead of a sum kernel and autograd's own seed (model_wrapper.py:158-160)
+        torch.autograd.backward([loss_d_real, loss_d_fake], ops.backward_seeds([loss_d_real, loss_d_fake]))
         self._finish_backward("d")
         return features_real, loss_d_real, loss_d_fake
 
@@ -201,12 +202,20 @@ class ModelWrapper(object):
         try:
             prediction_fake = D(images_fake, labels)
             loss_g = self.generator_loss(prediction_fake)
-            loss_div = w_div * self.diversity_loss(images_fake, noise_g)
+            # the weights ride inside this package's loss kernels; a caller's own loss module is weighted the reference's way
+            if isinstance(self.diversity_loss, DiversityLoss):
+                loss_div = self.diversity_loss(images_fake, noise_g, weight=w_div)
+            else:
+                loss_div = w_div * self.diversity_loss(images_fake, noise_g)
             features_fake = V(images_fake)
-            loss_rec = w_rec * self.semantic_reconstruction_loss(features_real, features_fake, masks)
+            if isinstance(self.semantic_reconstruction_loss, SemanticReconstructionLoss):
+                loss_rec = self.semantic_reconstruction_loss(features_real, features_fake, masks, weight=w_rec)
+            else:
+                loss_rec = w_rec * self.semantic_reconstruction_loss(features_real, features_fake, masks)
             self._arm_reducer("g")
-            seed = ops.loss_scale_seed(images_fake.device)      # the total is shape (1,) like the reference's (lossfunction.py:42)
-            (loss_g + loss_rec + loss_div).backward(gradient=seed.reshape(1) if seed is not None else None)
+            # backward of (loss_g + loss_rec + loss_div) (model_wrapper.py:187-188): one seed per term
+            terms = [loss_g, loss_rec, loss_div]
+            torch.autograd.backward(terms, ops.backward_seeds(terms))
             self._finish_backward("g")
         finally:
             for p in self._d_params:

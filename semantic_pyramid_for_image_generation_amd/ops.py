@@ -61,6 +61,32 @@ def loss_scale_seed(device) -> Optional[torch.Tensor]:
     return t
 
 
+def backward_seeds(losses) -> List[torch.Tensor]:
+    """grad_tensors for torch.autograd.backward(losses, ...): d(sum of the losses) / d(loss) = 1 (times the fp16 mode's static loss
+    scale) per loss, as cached tensors of each loss's shape - summing the losses first and letting autograd make its own seed costs
+    an add per loss, a fill and a reduction wherever the shapes differ (five tiny launches in the generator step)."""
+    s = loss_scale()
+    out = []
+    for t in losses:
+        key = (str(t.device), s, tuple(t.shape))
+        seed = _SCALE_SEED.get(key)
+        if seed is None:
+            seed = _SCALE_SEED[key] = torch.full(tuple(t.shape), s, dtype=torch.float32, device=t.device)
+        out.append(seed)
+    return out
+
+
+_LOSS_ACC = {}
+
+
+def _loss_acc(device) -> torch.Tensor:
+    """fp64 accumulators of the one-launch loss forms (include/sempyr.h: zero on entry, left zero): [0:2] diversity, [2] reconstruction."""
+    t = _LOSS_ACC.get(str(device))
+    if t is None:
+        t = _LOSS_ACC[str(device)] = torch.zeros(4, dtype=torch.float64, device=device)
+    return t
+
+
 def unscale_(flat: torch.Tensor, start: int = 0) -> None:
     """flat[start:] *= 1 / loss_scale(), in place, one launch of the library (no-op outside the fp16 mode).  The spectral-normalised
     layers' gradients lose the scale inside the batched backward (sp_sn_backward_batched_scaled); this is for the tail of a bank's
@@ -721,6 +747,13 @@ def _on_wgrad_stream(launch, tensors) -> None:
             t.record_stream(side)
 
 
+def _wgrad_aside(h: int, w: int) -> bool:
+    """CFG.wgrad_side_stream: 0 = never, 1 = every layer, N > 1 = layers whose maps have at most N pixels (the small-map layers, whose
+    weight-gradient and input-gradient launches each leave most CUs idle)."""
+    lim = CFG.wgrad_side_stream
+    return bool(lim) and (lim == 1 or h * w <= lim)
+
+
 def join_wgrad_stream(device) -> None:
     side = _WGRAD_STREAMS.get(device)
     if side is not None:
@@ -826,7 +859,7 @@ class _ConvFn(torch.autograd.Function):
                        cin_p, cout, cout_p, ksize, 1 if up2 else 0, sp_dtype(dt), stream())
             if KERNEL_PROBE is not None:
                 _probed("wgrad", 2.0 * n * h * w * cin_p * cout * ksize * ksize, False, launch_wgrad, (ksize, cin_p, cout, h, w, n))
-            elif CFG.wgrad_side_stream:
+            elif _wgrad_aside(h, w):
                 _on_wgrad_stream(launch_wgrad, [x, dz, ws])
             else:
                 launch_wgrad()
@@ -844,7 +877,7 @@ class _ConvFn(torch.autograd.Function):
                        ws_floats, n, h, w, cin_p, cout, cout_p, ksize, sp_dtype(dt), stream())
             if KERNEL_PROBE is not None:
                 _probed("wgrad", 2.0 * n * h * w * cin_p * cout * ksize * ksize, False, launch_wgrad, (ksize, cin_p, cout, h, w, n))
-            elif CFG.wgrad_side_stream and pl.call.bank.direct_grads:
+            elif _wgrad_aside(h, w) and pl.call.bank.direct_grads:
                 _on_wgrad_stream(launch_wgrad, [x, dz, ws])
             else:
                 launch_wgrad()
@@ -1579,7 +1612,7 @@ class _SqErrLossFn(torch.autograd.Function):
     def forward(ctx, p, target):
         require_gpu(p)
         p = p.contiguous().float()
-        acc = torch.empty(1, dtype=torch.float64, device=p.device)
+        acc = torch.empty(1, dtype=torch.float64, device=p.device)        # (used above 2^18 elements only; an allocation, no launch)
         loss = torch.empty((), dtype=torch.float32, device=p.device)
         L.call("sp_sqerr_loss_fwd", ptr(p), p.numel(), float(target), ptr(acc), ptr(loss), stream())
         ctx.target = float(target)
@@ -1607,32 +1640,45 @@ def _level_geometry(t: torch.Tensor):
 
 
 class _RecLossFn(torch.autograd.Function):
-    """sum over pyramid levels of mean(|maxpool2(real) - maxpool2(fake)| * maxpool2(mask))  (lossfunction.py:31-68).
-    Inputs after n_levels: fake features (differentiable); real features and masks are constants."""
+    """weight * sum over pyramid levels of mean(|maxpool2(real) - maxpool2(fake)| * maxpool2(mask))  (lossfunction.py:31-68), all
+    levels in ONE launch forward and ONE backward (sp_rec_loss_fwd_levels / _bwd_levels).  Inputs after (n_levels, weight): fake
+    features (differentiable); real features and masks are constants."""
 
     @staticmethod
-    def forward(ctx, n_levels, *tensors):
+    def _levels(prepared, dfakes=None):
+        arr = (L.SpRecLevel * len(prepared))()
+        for i, (f, r, m) in enumerate(prepared):
+            n, h, w, c, ld = _level_geometry(f)
+            lv = arr[i]
+            lv.real, lv.fake, lv.mask = r.data_ptr(), f.data_ptr(), m.data_ptr()
+            lv.ld_real, lv.ld_fake, lv.n, lv.h, lv.w_, lv.c = _level_geometry(r)[4], ld, n, h, w, c
+            if dfakes is not None and dfakes[i] is not None:
+                lv.dfake = dfakes[i].data_ptr()
+                lv.ld_dfake = c if f.dim() == 4 else dfakes[i].stride(0)
+        return arr
+
+    @staticmethod
+    def forward(ctx, n_levels, weight, *tensors):
         fakes = tensors[:n_levels]
         reals = tensors[n_levels:2 * n_levels]
         masks = tensors[2 * n_levels:]
         dev = fakes[0].device
         require_gpu(fakes[0])
-        acc = torch.zeros(1, dtype=torch.float64, device=dev)
+        dt = fakes[0].dtype
         prepared = []
         for f, r, m in zip(fakes, reals, masks):
-            dt = f.dtype
+            if f.dtype != dt:
+                raise L.SempyrError("semantic reconstruction loss: the levels must share one storage type")
             if f.dim() == 4:
                 f, r = as_nhwc(f), as_nhwc(r.detach(), dt)
             else:
                 f, r = as_rows(f), as_rows(r.detach(), dt)
-            m = m.detach().to(torch.float32).contiguous()
-            n, h, w, c, ld = _level_geometry(f)
-            ldr = _level_geometry(r)[4]
-            L.call("sp_rec_loss_fwd", ptr(r), ldr, ptr(f), ld, ptr(m), n, h, w, c, ptr(acc), sp_dtype(dt), stream())
-            prepared.append((f, r, m))
+            prepared.append((f, r, m.detach().to(torch.float32).contiguous()))
         loss = torch.empty(1, dtype=torch.float32, device=dev)       # the reference's loss is shape (1,) (lossfunction.py:42)
-        L.call("sp_f64_to_f32", ptr(acc), ptr(loss), 1, stream())
-        ctx.n_levels = n_levels
+        acc = _loss_acc(dev)
+        L.call("sp_rec_loss_fwd_levels", _RecLossFn._levels(prepared), n_levels, ctypes.c_void_p(acc.data_ptr() + 16), ptr(loss),
+               float(weight), sp_dtype(dt), stream())
+        ctx.n_levels, ctx.weight = n_levels, float(weight)
         ctx.save_for_backward(*[t for trip in prepared for t in trip])
         return loss
 
@@ -1640,31 +1686,32 @@ class _RecLossFn(torch.autograd.Function):
     def backward(ctx, g):
         saved = ctx.saved_tensors
         g = g.contiguous().float()
-        grads = []
+        prepared, dfakes = [], []
         for i in range(ctx.n_levels):
-            f, r, m = saved[3 * i:3 * i + 3]
-            if not ctx.needs_input_grad[1 + i]:
-                grads.append(None)
+            if not ctx.needs_input_grad[2 + i]:
                 continue
+            f, r, m = saved[3 * i:3 * i + 3]
             n, h, w, c, ld = _level_geometry(f)
-            ldr = _level_geometry(r)[4]
-            df = torch.empty_like(f) if f.dim() == 4 else torch.empty((n, c), dtype=f.dtype, device=f.device)
-            L.call("sp_rec_loss_bwd", ptr(r), ldr, ptr(f), ld, ptr(m), ptr(g), ptr(df), c if f.dim() == 4 else df.stride(0), n, h, w, c,
-                   sp_dtype(f.dtype), stream())
-            grads.append(df)
-        return (None, *grads, *([None] * (2 * ctx.n_levels)))
+            prepared.append((f, r, m))
+            dfakes.append(torch.empty_like(f) if f.dim() == 4 else torch.empty((n, c), dtype=f.dtype, device=f.device))
+        if prepared:
+            L.call("sp_rec_loss_bwd_levels", _RecLossFn._levels(prepared, dfakes), len(prepared), ptr(g), ctx.weight,
+                   sp_dtype(prepared[0][0].dtype), stream())
+        it = iter(dfakes)
+        grads = [next(it) if ctx.needs_input_grad[2 + i] else None for i in range(ctx.n_levels)]
+        return (None, None, *grads, *([None] * (2 * ctx.n_levels)))
 
 
-def semantic_reconstruction_loss(features_real, features_fake, masks):
+def semantic_reconstruction_loss(features_real, features_fake, masks, weight: float = 1.0):
     n = len(features_fake)
-    return _RecLossFn.apply(n, *features_fake, *features_real, *masks)
+    return _RecLossFn.apply(n, weight, *features_fake, *features_real, *masks)
 
 
 class _DivLossFn(torch.autograd.Function):
     """mean|z1 - z2| / (mean|img1 - img2| + 1e-8) over the two halves of the batch (lossfunction.py:92-110)."""
 
     @staticmethod
-    def forward(ctx, img, z):
+    def forward(ctx, img, z, weight):
         require_gpu(img)
         b = img.shape[0]
         if b < 2 or b % 2:
@@ -1672,11 +1719,11 @@ class _DivLossFn(torch.autograd.Function):
         img = as_nhwc(img)
         z = z.detach().to(torch.float32).contiguous()
         half = img.numel() // 2
-        acc = torch.empty(2, dtype=torch.float64, device=img.device)
-        out = torch.empty(2, dtype=torch.float32, device=img.device)
-        L.call("sp_div_loss_fwd", ptr(img), half, ptr(z), z.numel() // 2, ptr(acc), ptr(out), sp_dtype(img.dtype), stream())
+        out = torch.empty(2, dtype=torch.float32, device=img.device)      # weight * (loss, d loss / d |img1 - img2| per element)
+        L.call("sp_div_loss_fwd_w", ptr(img), half, ptr(z), z.numel() // 2, ptr(_loss_acc(img.device)), ptr(out), float(weight),
+               sp_dtype(img.dtype), stream())
         ctx.save_for_backward(img, out)
-        return out[0].clone()
+        return out[0]
 
     @staticmethod
     def backward(ctx, g):
@@ -1684,11 +1731,11 @@ class _DivLossFn(torch.autograd.Function):
         g = g.contiguous().float()
         dimg = torch.empty_like(img)
         L.call("sp_div_loss_bwd", ptr(img), img.numel() // 2, ptr(out), ptr(g), ptr(dimg), sp_dtype(img.dtype), stream())
-        return dimg, None
+        return dimg, None, None
 
 
-def diversity_loss(img, z):
-    return _DivLossFn.apply(img, z)
+def diversity_loss(img, z, weight: float = 1.0):
+    return _DivLossFn.apply(img, z, weight)
 
 
 # ======================================================================================================

@@ -490,8 +490,11 @@ def test_conv_linearity_property_full_size():
 # linear
 # ----------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("case", [(128, 128, 2), (365, 2048, 4), (4096, 365, 3), (768, 128, 20)])
+@pytest.mark.parametrize("case", [(128, 128, 2), (365, 2048, 4), (4096, 365, 3), (768, 128, 20), (512, 130, 20), (1000, 128, 32), (1024, 256, 7),
+                                  (136, 77, 5), (1536, 128, 20), (128, 16384, 20)])
 def test_sn_linear(case, dtype):
+    """(16-bit storage: rows of up to 1024 values finish in one launch - the single K-split applies the epilogue itself -, longer
+    rows go through slabs + the finalize pass: csrc/linear.hip)"""
     k, n, b = case
     ops.set_compute_dtype(dtype)
     m = models.SNLinear(k, n).cuda()
@@ -781,6 +784,22 @@ def test_discriminator_head_and_lsgan(dtype):
     close(D.classification.bias.grad, S["classification.bias"].grad, 2 * tol, "dbc")
 
 
+@pytest.mark.parametrize("n", [1, 7, 4096, 51200, 51203, (1 << 18) + 5, 1 << 20])
+def test_sqerr_loss_sizes(n):
+    """0.5 * mean((p - t)^2) (lossfunction.py:137,164): the one-block form (up to 2^18 elements; vector body + scalar tail, also from
+    an address that is not 16-byte aligned) and the multi-block form agree with torch in fp64."""
+    ops.set_compute_dtype(torch.float32)
+    base = torch.randn(n + 1, device="cuda", generator=torch.Generator(device="cuda").manual_seed(n))
+    for off in (0, 1):
+        p = base[off:off + n].clone() if off == 0 else base[1:1 + n]
+        p = p.detach().requires_grad_(True)
+        loss = ops.sqerr_loss(p, 1.0)
+        loss.backward(torch.tensor(2.0, device="cuda"))
+        want = 0.5 * ((p.detach().double() - 1.0) ** 2).mean()
+        assert abs(float(loss) - float(want)) <= 2e-6 * max(1.0, float(want))
+        close(p.grad, (2.0 * (p.detach() - 1.0) / n).cpu(), 1e-6, "dp")
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_reconstruction_and_diversity_losses(dtype):
     ops.set_compute_dtype(dtype)
@@ -807,6 +826,29 @@ def test_reconstruction_and_diversity_losses(dtype):
     dl.backward()
     close(dl, dref, 1e-5 if dtype == torch.float32 else 1e-3, "div loss")
     close(imgd.grad, img.grad, 1e-5 if dtype == torch.float32 else 2e-2, "div grad")
+    # the caller's weight folded into the kernels (ModelWrapper: w_rec, w_div), an upstream gradient != 1, and repeated calls: the
+    # shared fp64 accumulators of the one-launch forms must be back at zero after every call
+    for _ in range(2):
+        fd2 = [dev(f, dtype).requires_grad_(True) for f in fake]
+        lw = ops.semantic_reconstruction_loss([dev(r, dtype) for r in real], fd2, [m.cuda() for m in masks], weight=0.1)
+        lw.backward(gradient=torch.full((1,), 3.0, device="cuda"))
+        close(lw, 0.1 * ref.detach(), 1e-5 if dtype == torch.float32 else 1e-3, "weighted rec loss")
+        for a_, b_ in zip(fd2, fake):
+            close(a_.grad, 0.3 * b_.grad, 1e-6 if dtype == torch.float32 else 1e-2, "weighted rec grad")
+        img2 = dev(img, dtype).requires_grad_(True)
+        dw = ops.diversity_loss(img2, z.cuda(), weight=0.25)
+        dw.backward(gradient=torch.tensor(2.0, device="cuda"))
+        close(dw, 0.25 * dref.detach(), 1e-5 if dtype == torch.float32 else 1e-3, "weighted div loss")
+        close(img2.grad, 0.5 * img.grad, 1e-5 if dtype == torch.float32 else 2e-2, "weighted div grad")
+    assert float(ops._loss_acc(torch.device("cuda", torch.cuda.current_device())).abs().max()) == 0.0
+    # only some levels need a gradient
+    fd3 = [dev(f, dtype).requires_grad_(i % 2 == 0) for i, f in enumerate(fake)]
+    ops.semantic_reconstruction_loss([dev(r, dtype) for r in real], fd3, [m.cuda() for m in masks]).backward()
+    for i, (a_, b_) in enumerate(zip(fd3, fake)):
+        if i % 2 == 0:
+            close(a_.grad, b_.grad, 1e-6 if dtype == torch.float32 else 1e-2, "rec grad (subset)")
+        else:
+            assert a_.grad is None
 
 
 # ----------------------------------------------------------------------------------------------
