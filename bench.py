@@ -55,6 +55,9 @@ def parse():
                         "(BASELINE config 5's activations; static loss scale)")
     p.add_argument("--fp8", action="store_true", help="BASELINE config 5: e4m3 operands on the fp8 MFMA for the VGG-16 pyramid's wide 3x3 "
                                                       "layers in the no-gradient pass (ops.set_vgg_fp8(1)); with --dtype fp16 this is the config-5 line")
+    p.add_argument("--deterministic", action="store_true",
+                   help="SP_TUNE_DETERMINISTIC=1: every reduction in a fixed order also in the 16-bit modes (no fp32 atomics in the small-map "
+                        "weight gradients): two runs give identical bits; the default line reports this mode's cost as `deterministic`")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-probe", action="store_true")
     p.add_argument("--no-sub-records", action="store_true", help="skip the fp32 parity-mode and batch-32 sub-records")
@@ -263,9 +266,10 @@ def gpu_blocker(ms: float) -> None:
 
 
 def nonconv_floor():
-    """Kernel time per step of everything that is NOT a probed convolution launch, from the committed rocprofv3 summary of the same
-    command (profiles/<round>_nonconv_floor.json, written by profiles/extract_floor.py from the kernel-trace CSV): the sanity
-    check of the probe needs it, the process cannot profile itself.  (ms, provenance) or (0.0, None)."""
+    """Kernel time per step of everything that is NOT a probed convolution launch, from the committed rocprofv3 kernel trace of the
+    same command (profiles/<round>_nonconv_floor.json, written by profiles/step_timeline.py --floor from the last three replayed
+    steps, with the profiler's per-launch excess over the plain step of the same box taken off): the sanity check of the probe needs
+    it, the process cannot profile itself.  (ms, provenance) or (0.0, None)."""
     import hashlib
     for name in FLOOR_FILES:
         path = os.path.join(ROOT, "profiles", name)
@@ -273,7 +277,8 @@ def nonconv_floor():
             raw = open(path, "rb").read()
             rec = json.loads(raw)
             return float(rec["nonconv_ms_per_step"]), {"file": "profiles/" + name, "sha256_16": hashlib.sha256(raw).hexdigest()[:16],
-                                                       "steps_profiled": rec.get("steps"), "launches_per_step": rec.get("launches_per_step")}
+                                                       "steps_profiled": rec.get("steps"), "launches_per_step": rec.get("launches_per_step"),
+                                                       "profiled_on_a_box_whose_plain_step_was_ms": rec.get("plain_step_ms")}
         except (OSError, ValueError, KeyError):
             continue
     return 0.0, None
@@ -590,6 +595,9 @@ def main():
     if args.fp8:
         from semantic_pyramid_for_image_generation_amd import ops as _ops0
         _ops0.set_vgg_fp8(1)
+    if args.deterministic:
+        from semantic_pyramid_for_image_generation_amd import ops as _ops1
+        _ops1.set_tuning(_ops1.TUNE_DETERMINISTIC, 1)
     job = Job(cf, args.batch, args.dtype, dev, world, rank, not args.no_graphs, args.device_masks)
     elapsed, losses = job.timed(args.steps, args.warmup)
     # the probe runs extra training steps: with world > 1 they contain collectives, so EVERY rank takes them
@@ -618,7 +626,7 @@ def main():
             "config": {"workload": "Semantic-Pyramid GAN D+G step, channel_factor=%g, 256x256x3, batch %d/GPU, Adam lr 1e-5, "
                                    "random-init G/D, kaiming-init frozen VGG-16" % (cf, args.batch),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                       "launch": launch_mode, "masks": "fresh on-device batch per step" if args.device_masks else "one resident batch",
+                       "launch": launch_mode, "deterministic": bool(args.deterministic or args.dtype == "f32"), "masks": "fresh on-device batch per step" if args.device_masks else "one resident batch",
                        "losses_last_step": losses},
             "roofline": {"bound": "mfma", "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None, "traffic": None,
                          "basis": "achieved / frac: FLOP-weighted over every convolution launch of a step (forward + input gradient + weight "
@@ -677,6 +685,18 @@ def main():
             if args.batch != 32:
                 line["batch32"] = sub_record(cf, 32, args.dtype, dev, 15, 5, not args.no_graphs)
                 line["batch32"]["note"] = "BASELINE.json config 2: one MI355X, batch 32"
+        if world == 1 and not args.no_sub_records and args.dtype != "f32" and not args.deterministic:
+            # the same step with every reduction in a fixed order (bit-identical from run to run, tests/test_gpu_step.py): its price
+            from semantic_pyramid_for_image_generation_amd import ops as _ops2
+            _ops2.set_tuning(_ops2.TUNE_DETERMINISTIC, 1)
+            try:
+                line["deterministic"] = sub_record(cf, args.batch, args.dtype, dev, 15, 5, not args.no_graphs)
+                line["deterministic"]["vs_headline"] = round(line["deterministic"]["value"] / ips, 4)
+                line["deterministic"]["note"] = "SP_TUNE_DETERMINISTIC=1 (bench.py --deterministic): no fp32 atomics anywhere in the step"
+            except Exception as exc:
+                line["deterministic"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            finally:
+                _ops2.set_tuning(_ops2.TUNE_DETERMINISTIC, -1)
         if world == 1 and not args.no_sub_records and args.dtype == "bf16" and cf == 1:
             try:
                 line["bf16_parity"] = bf16_parity_record(dev)

@@ -1,10 +1,22 @@
 """Timeline of ONE replayed training step from a rocprofv3 --kernel-trace CSV: the kernels in start order, with the idle gap in
 front of each, summed per phase of the step (the phases are cut at the two adam_multi launches: discriminator step | generator
-step) and per kernel symbol.  Usage: python profiles/step_timeline.py <kernel_trace.csv> [--list]"""
+step) and per kernel symbol.  Usage: python profiles/step_timeline.py <kernel_trace.csv> [--list]
+
+    python profiles/step_timeline.py <kernel_trace.csv> --floor PLAIN_STEP_MS > profiles/roundN_nonconv_floor.json
+
+writes the record bench.py's probe check reads: the kernel time of everything that is not a probed convolution launch, per step,
+over the last three replayed steps of the trace.  PLAIN_STEP_MS = ms_per_step of the same command on the same box WITHOUT the
+profiler: under --kernel-trace every launch is ~3 us longer than in the replayed graph (a launch that computes nothing shows as
+4.7 us; 100 of them added to the replayed step cost 1.57 us each - profiles/README.md), so the profiled total exceeds the plain step
+although the GPU is never idle in either.  The excess, spread evenly over the launches, is taken off the non-convolution total."""
 import collections
 import csv
+import json
 import re
 import sys
+
+# the kernels behind sp_conv2d_igemm / sp_conv2d_wgrad* (the launches bench.py brackets with events), incl. their finalize / reduce passes
+CONV = re.compile(r"conv3x3_|conv1x1_|conv_igemm|conv_finalize|conv_wgrad|wgrad1x1_|wgrad3x3_|wgrad_reduce|conv_wgrad_rows_reduce")
 
 
 def short(name):
@@ -17,8 +29,25 @@ def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
     ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows), key=lambda e: e[0])
     adam = [i for i, e in enumerate(ev) if "adam_multi" in e[2]]
-    if len(adam) < 6:
-        sys.exit("need at least three steps in the trace")
+    if len(adam) < 8:
+        sys.exit("need at least four steps in the trace")
+    if "--floor" in sys.argv:
+        plain_ms = float(sys.argv[sys.argv.index("--floor") + 1])
+        nsteps = 3
+        span = ev[adam[-1 - 2 * nsteps] + 1:adam[-1] + 1]           # the last three steps (two adam launches each)
+        conv = [e for e in span if CONV.search(e[2])]
+        other = [e for e in span if not CONV.search(e[2])]
+        conv_ms = sum(e[1] - e[0] for e in conv) / 1e6 / nsteps
+        other_ms = sum(e[1] - e[0] for e in other) / 1e6 / nsteps
+        launches = len(span) / nsteps
+        inflation_us = max(0.0, (conv_ms + other_ms - plain_ms) * 1e3 / launches)
+        print(json.dumps({"source": "rocprofv3 --kernel-trace of `bench.py` (graph replay), last %d steps" % nsteps, "steps": nsteps,
+                          "plain_step_ms": plain_ms, "profiled_kernel_ms_per_step": round(conv_ms + other_ms, 4),
+                          "profiler_inflation_us_per_launch": round(inflation_us, 3),
+                          "launches_per_step": round(launches, 1), "nonconv_launches_per_step": round(len(other) / nsteps, 1),
+                          "conv_ms_per_step_profiled": round(conv_ms, 4), "nonconv_ms_per_step_profiled": round(other_ms, 4),
+                          "nonconv_ms_per_step": round(other_ms - len(other) / nsteps * inflation_us / 1e3, 4)}, indent=1))
+        return
     # the last complete step: from just after the G-adam of step n-2 to the G-adam of step n-1 (adam launches alternate D, G)
     a0, a1, a2 = adam[-3], adam[-2], adam[-1]
     step = ev[a0 + 1:a2 + 1]

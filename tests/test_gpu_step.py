@@ -263,6 +263,21 @@ def test_graphed_step_matches_eager_step_bf16():
     assert float((graphed["pixels"] - eager["pixels"]).abs().max()) <= 2e-2 * 2.0
 
 
+def test_graphed_step_matches_eager_step_bf16_deterministic():
+    """SP_TUNE_DETERMINISTIC = 1 (bench.py --deterministic): the 16-bit mode with every reduction in a fixed order - replay and eager
+    launches must then agree EXACTLY, like the fp32 mode does by default."""
+    ops.set_tuning(ops.TUNE_DETERMINISTIC, 1)
+    try:
+        eager, graphed = _eager_vs_graphed(torch.bfloat16, "step_cf1_b2_seed0")
+    finally:
+        ops.set_tuning(ops.TUNE_DETERMINISTIC, -1)
+    for k in LOSS_NAMES:
+        assert graphed[k] == eager[k], (k, graphed[k], eager[k])
+    assert torch.equal(graphed["pixels"], eager["pixels"])
+    for k in eager["G"]:
+        assert torch.equal(graphed["G"][k], eager["G"][k]), k
+
+
 def test_eval_mode_generator_forward_vs_oracle():
     """Row f2: the inference path of model_wrapper.py:247-296 - generator.eval(): spectral norm WITHOUT a power iteration
     (u, v untouched), BatchNorm with the running statistics, batch of one - against the oracle's eval semantics (fp32)."""
