@@ -64,31 +64,56 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const T* __restrict__
                                                            float* __restrict__ dw, int kp, float* __restrict__ db, int B,
                                                            int K, int N) {
     // a thread owns FOUR consecutive columns k .. k + 3 of LW_NR consecutive rows: x[b][k..] is loaded once per batch row (8 / 16
-    // bytes) and reused for all rows (dy[b][n] is block-uniform), the fp32 results leave as 16-byte stores.  History: one row per
-    // thread re-read x for every output row (86 us on the 4096 x 2048 layer); one column per thread stored 4 bytes per lane (24.6 us,
-    // 1.4 TB/s for the 33 MB of output that are the floor); this form: round 4.
+    // bytes) and reused for all rows, the fp32 results leave as 16-byte stores.  The dy[b][n0..n0+8) values every thread needs are
+    // staged in LDS once, and the x loads of four batch rows are in flight together: the plain loop over the batch was a chain of
+    // B dependent round trips (load -> wait -> 32 FMAs), 24 us for a layer whose operands and output are a few megabytes.
+    // History: one row per thread re-read x for every output row (86 us on the 4096 x 2048 layer); one column per thread stored
+    // 4 bytes per lane (24.6 us); four columns per thread: 24.1 us (not store bound either); this form: round 4.
+    __shared__ float dys[32][LW_NR];
     const int k = (blockIdx.x * 256 + threadIdx.x) * 4;
     const int n0 = blockIdx.y * LW_NR;
-    if (k >= kp) return;
+    const bool live = k < kp;
     float acc[LW_NR][4], bs[LW_NR];
 #pragma unroll
     for (int j = 0; j < LW_NR; ++j) { acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.f; bs[j] = 0.f; }
     const bool vec = k + 4 <= K && ((ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-    for (int b = 0; b < B; ++b) {
-        float xv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (vec) Elem<T>::ld4(x + (long)b * ldx + k, xv);
-        else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) if (k + q < K) xv[q] = Elem<T>::ld(x + (long)b * ldx + k + q);
+    for (int b0 = 0; b0 < B; b0 += 32) {
+        const int nb = min(32, B - b0);
+        __syncthreads();
+        {
+            const int bb = threadIdx.x / LW_NR, j = threadIdx.x % LW_NR;
+            dys[bb][j] = (bb < nb && n0 + j < N) ? Elem<T>::ld(dy + (long)(b0 + bb) * ldd + n0 + j) : 0.f;
         }
+        __syncthreads();
+        if (!live) continue;
+        for (int b = 0; b < nb; b += 4) {
+            float xv[4][4];
 #pragma unroll
-        for (int j = 0; j < LW_NR; ++j) {
-            const float d = n0 + j < N ? Elem<T>::ld(dy + (long)b * ldd + n0 + j) : 0.f;
-            bs[j] += d;
+            for (int u = 0; u < 4; ++u) {
+                xv[u][0] = xv[u][1] = xv[u][2] = xv[u][3] = 0.f;
+                if (b + u < nb) {
+                    const T* xr = x + (long)(b0 + b + u) * ldx + k;
+                    if (vec) Elem<T>::ld4(xr, xv[u]);
+                    else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[j][q] += d * xv[q];
+                        for (int q = 0; q < 4; ++q) if (k + q < K) xv[u][q] = Elem<T>::ld(xr + q);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (b + u >= nb) break;
+#pragma unroll
+                for (int j = 0; j < LW_NR; ++j) {
+                    const float d = dys[b + u][j];
+                    bs[j] += d;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[j][q] += d * xv[u][q];
+                }
+            }
         }
     }
+    if (!live) return;
 #pragma unroll
     for (int j = 0; j < LW_NR; ++j) {
         if (n0 + j >= N) break;
@@ -96,7 +121,6 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const T* __restrict__
         if (db && k == 0) db[n0 + j] = bs[j];
     }
 }
-
 
 // ---- bf16 MFMA split-K path for the big weight matrices (VGG classifier 25088x4096 / 4096x4096, G 4096x2048):
 // D[n][b] += sum_{k in slice} Wp[n][k] x[b][k].  The weight rows are the MFMA A operand and are read straight from

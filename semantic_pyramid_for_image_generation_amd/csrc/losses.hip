@@ -43,33 +43,66 @@ template <typename T>
 __global__ void dhead_bwd_kernel(const float* __restrict__ dpred, const T* __restrict__ x, int ldx, const float* __restrict__ E,
                                  const int64_t* __restrict__ cls, const float* __restrict__ wc, T* __restrict__ dx, int lddx,
                                  float* __restrict__ dE, float* __restrict__ sdp_out, int B, int F) {
+    // Every loop below walks the batch with two loads per trip; written plainly each trip waited for its own loads (~50 dependent
+    // round trips, 18 - 23 us per launch for a few hundred kilobytes).  The class indices sit in LDS and the loads of FOUR trips are
+    // issued together; the additions keep their order (results are bit-identical).
     __shared__ float red[4];
+    __shared__ int cls_s[1024];                                // (the entry point admits batch <= 1024)
     const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < B; i += 256) cls_s[i] = (int)cls[i];
     {
         float a = 0.f;
-        for (int e = threadIdx.x; e < B * F; e += 256) {       // (i, c) pairs of column b
-            const int i = e / F, c = e - i * F;
-            a += dpred[((long)i * B + b) * F + c];
+        const int total = B * F;
+        for (int e0 = threadIdx.x; e0 < total; e0 += 4 * 256) {       // (i, c) pairs of column b
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * 256;
+                const int i = e / F, c = e - i * F;
+                v[u] = e < total ? dpred[((long)i * B + b) * F + c] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (e0 + u * 256 < total) a += v[u];
         }
         a = wave_sum(a);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
     }
     __syncthreads();
     const float sdp_b = red[0] + red[1] + red[2] + red[3];
-    const int64_t my_cls = cls[b];
+    const int my_cls = cls_s[b];
     bool first = true;
-    for (int i = 0; i < b; ++i) first = first && cls[i] != my_cls;      // block-uniform
+    for (int i = 0; i < b; ++i) first = first && cls_s[i] != my_cls;      // block-uniform
     for (int c = threadIdx.x; c < F; c += 256) {
         float a = wc[c] * sdp_b;                               // dx[b][c]
-        for (int i = 0; i < B; ++i) a += dpred[((long)i * B + b) * F + c] * E[cls[i] * F + c];
+        for (int i0 = 0; i0 < B; i0 += 4) {
+            float dp[4], ev[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u;
+                dp[u] = i < B ? dpred[((long)i * B + b) * F + c] : 0.f;
+                ev[u] = i < B ? E[(long)cls_s[i] * F + c] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (i0 + u < B) a += dp[u] * ev[u];
+        }
         Elem<T>::st(dx + (long)b * lddx + c, a);
         if (first) {
             float g = 0.f;                                     // dE[k][c] = sum_{i: cls[i] = k} sum_j dpred[i][j][c] * x[j][c]
             for (int i = b; i < B; ++i) {
-                if (cls[i] != my_cls) continue;
-                for (int j = 0; j < B; ++j) g += dpred[((long)i * B + j) * F + c] * Elem<T>::ld(x + (long)j * ldx + c);
+                if (cls_s[i] != my_cls) continue;
+                for (int j0 = 0; j0 < B; j0 += 4) {
+                    float dp[4], xv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int j = j0 + u;
+                        dp[u] = j < B ? dpred[((long)i * B + j) * F + c] : 0.f;
+                        xv[u] = j < B ? Elem<T>::ld(x + (long)j * ldx + c) : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (j0 + u < B) g += dp[u] * xv[u];
+                }
             }
-            dE[my_cls * F + c] += g;
+            dE[(long)my_cls * F + c] += g;
         }
     }
     if (threadIdx.x == 0) sdp_out[b] = sdp_b;
