@@ -19,5 +19,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_graph -- pyth
 cd /root/repo
 cp $(ls $OUT/trace_graph/*/*kernel_stats.csv | head -1) $OUT/kernel_stats_graph.csv
 rm -rf $OUT/trace_graph
-python3 profiles/extract_floor.py $OUT/kernel_stats.csv 10 > $OUT/nonconv_floor.json
+# (the probe's non-convolution floor: scratch/floor.sh - plain step + kernel trace of the replayed steps on one box)
 ls -la $OUT
