@@ -320,6 +320,29 @@ __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const float* __restri
 // grid.y = layer, blocks past a layer's extent exit.  dots are zero-filled by the caller (they live in the same arena as
 // the dW slots, which the caller zero-fills once per backward pass).
 constexpr int SN_DOT_BLOCKS = 512;      // blocks (= partial sums) per layer of the batched dot kernel
+// 3x3 layers: dWsn arrives in the forward packing [row][tap][cin_p], W and the gradient are [row][cin][tap].  Read element by element
+// in the destination's order, a wave gathers seven floats from each of nine tap planes per load (the apply kernel ran at 2.3 TB/s).
+// Here a work item is (row, chunk of 256 input channels): the nine tap rows of the chunk are read as they lie (thread = channel),
+// turned in LDS ([channel][tap], pitch 9 floats: odd, conflict-free), and everything in the destination's order - W, v, the
+// gradient - is then one contiguous run of up to 2 304 floats.
+constexpr int SN_TR_CI = 256, SN_TR_MAXTAPS = 9;
+__device__ __forceinline__ int sn_tr_chunks(const sp_sn_bwd_layer& L) { return (L.cin + SN_TR_CI - 1) / SN_TR_CI; }
+// stages chunk `ch` of row r into tile[]; returns the number of floats staged (channels x taps); callers __syncthreads() around it
+__device__ __forceinline__ int sn_tr_stage(const sp_sn_bwd_layer& L, const float* __restrict__ dwsn, int r, int ch, float* tile) {
+    const int ci0 = ch * SN_TR_CI, nci = min(SN_TR_CI, L.cin - ci0);
+    const int t = threadIdx.x;
+    if (t < nci) {
+        float v[SN_TR_MAXTAPS];
+#pragma unroll
+        for (int tap = 0; tap < SN_TR_MAXTAPS; ++tap)
+            v[tap] = tap < L.taps ? dwsn[((long)r * L.taps + tap) * L.cin_p + ci0 + t] : 0.f;
+#pragma unroll
+        for (int tap = 0; tap < SN_TR_MAXTAPS; ++tap)
+            if (tap < L.taps) tile[t * L.taps + tap] = v[tap];
+    }
+    return nci * L.taps;
+}
+
 __global__ __launch_bounds__(256) void sn_bwd_dot_batched_kernel(const sp_sn_bwd_layer* __restrict__ table, const float* __restrict__ arena,
                                                                  float* __restrict__ dot_partials) {
     const sp_sn_bwd_layer L = table[blockIdx.y];
@@ -327,16 +350,37 @@ __global__ __launch_bounds__(256) void sn_bwd_dot_batched_kernel(const sp_sn_bwd
     const long nb = min((long)gridDim.x, (total + 1023) / 1024);      // blocks working on this layer
     if ((long)blockIdx.x >= nb) return;
     __shared__ float red[4];
+    __shared__ __attribute__((aligned(16))) float tile[SN_TR_CI * SN_TR_MAXTAPS];
     const float* dwsn = arena + L.dw_off;
     float part = 0.f;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += nb * 256) {
-        long src = e;
-        if (!L.plain) {
-            const int r = (int)(e / L.cols), c = (int)(e % L.cols);
-            const int ci = c / L.taps, tap = c - ci * L.taps;
-            src = ((long)r * L.taps + tap) * L.cin_p + ci;
+    if (!L.plain && L.taps > 1 && L.taps <= SN_TR_MAXTAPS) {
+        const int chunks = sn_tr_chunks(L);
+        const long items = (long)L.rows * chunks;
+        for (long it = blockIdx.x; it < items; it += nb) {
+            const int r = (int)(it / chunks), ch = (int)(it - (long)r * chunks);
+            __syncthreads();
+            const int cnt = sn_tr_stage(L, dwsn, r, ch, tile);
+            __syncthreads();
+            const float* wrow = L.w + (long)r * L.cols + (long)ch * SN_TR_CI * L.taps;
+            if (((L.cols | cnt) & 3) == 0 && (reinterpret_cast<uintptr_t>(L.w) & 15) == 0) {      // 16-byte runs (every layer but the RGB one)
+                for (int q = threadIdx.x * 4; q < cnt; q += 1024) {
+                    const float4 a = *reinterpret_cast<const float4*>(tile + q), wv = *reinterpret_cast<const float4*>(wrow + q);
+                    part += (a.x * wv.x + a.y * wv.y) + (a.z * wv.z + a.w * wv.w);
+                }
+            } else {
+                for (int q = threadIdx.x; q < cnt; q += 256) part += tile[q] * wrow[q];
+            }
         }
-        part += dwsn[src] * L.w[e];
+    } else {
+        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += nb * 256) {
+            long src = e;
+            if (!L.plain) {
+                const int r = (int)(e / L.cols), c = (int)(e % L.cols);
+                const int ci = c / L.taps, tap = c - ci * L.taps;
+                src = ((long)r * L.taps + tap) * L.cin_p + ci;
+            }
+            part += dwsn[src] * L.w[e];
+        }
     }
     const float tot = block_sum_256(part, red);
     if (threadIdx.x == 0) dot_partials[(long)blockIdx.y * SN_DOT_BLOCKS + blockIdx.x] = tot;     // summed in block order by the apply kernel
@@ -367,6 +411,39 @@ __global__ __launch_bounds__(256) void sn_bwd_apply_batched_kernel(const sp_sn_b
     const float coef = dot * inv_sigma;                    // <dwsn, W/sigma>
     float* grad = grads + L.grad_off;
     const float* acc = prev ? prev + L.grad_off : nullptr;    // may alias grad: every element is read, then written, by one thread
+    if (!L.plain && L.taps > 1 && L.taps <= SN_TR_MAXTAPS) {
+        __shared__ __attribute__((aligned(16))) float tile[SN_TR_CI * SN_TR_MAXTAPS];
+        const int chunks = sn_tr_chunks(L);
+        const long items = (long)L.rows * chunks;
+        for (long it = blockIdx.x; it < items; it += nb) {
+            const int r = (int)(it / chunks), ch = (int)(it - (long)r * chunks);
+            __syncthreads();
+            const int cnt = sn_tr_stage(L, dwsn, r, ch, tile);
+            __syncthreads();
+            const int c0 = ch * SN_TR_CI * L.taps;
+            const long e0 = (long)r * L.cols + c0;
+            const float cu = coef * usnap[r];
+            if (((L.cols | cnt | (int)(L.grad_off & 3) | (int)(L.scratch_off & 3)) & 3) == 0 && (reinterpret_cast<uintptr_t>(grads) & 15) == 0 &&
+                (reinterpret_cast<uintptr_t>(scratch) & 15) == 0 && (acc == nullptr || (reinterpret_cast<uintptr_t>(prev) & 15) == 0)) {
+                for (int q = threadIdx.x * 4; q < cnt; q += 1024) {
+                    const float4 a = *reinterpret_cast<const float4*>(tile + q), vv = *reinterpret_cast<const float4*>(vsnap + c0 + q);
+                    float4 g4;
+                    g4.x = (a.x - cu * vv.x) * inv_sigma * grad_scale;
+                    g4.y = (a.y - cu * vv.y) * inv_sigma * grad_scale;
+                    g4.z = (a.z - cu * vv.z) * inv_sigma * grad_scale;
+                    g4.w = (a.w - cu * vv.w) * inv_sigma * grad_scale;
+                    if (acc) { const float4 p4 = *reinterpret_cast<const float4*>(acc + e0 + q); g4.x += p4.x; g4.y += p4.y; g4.z += p4.z; g4.w += p4.w; }
+                    *reinterpret_cast<float4*>(grad + e0 + q) = g4;
+                }
+            } else {
+                for (int q = threadIdx.x; q < cnt; q += 256) {
+                    const float gv = (tile[q] - cu * vsnap[c0 + q]) * inv_sigma * grad_scale;
+                    grad[e0 + q] = acc ? acc[e0 + q] + gv : gv;
+                }
+            }
+        }
+        return;
+    }
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += nb * 256) {
         const int r = (int)(e / L.cols), c = (int)(e % L.cols);
         long src = e;
