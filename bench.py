@@ -428,7 +428,9 @@ class Job:
             return synthetic.training_masks_device(batch, dev, mask_gen) if device_masks else masks
 
         def eager_step():
-            return mw.train_step(images, labels, fresh_masks())
+            # the resident batch is also the NEXT iteration's batch: its VGG pyramid rides in this iteration's pass over the fake images
+            # (ModelWrapper.train_step: next_images_real), as it does for consecutive batches in ModelWrapper.train()
+            return mw.train_step(images, labels, fresh_masks(), next_images_real=images)
         self.eager_step = eager_step
         self.step = eager_step
         self.launch_mode = "eager"

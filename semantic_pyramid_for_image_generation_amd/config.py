@@ -20,6 +20,7 @@ results beyond floating-point summation order.  The kernel library itself reads 
     side_features         SP_SIDE_FEATURES       0        the generator's masked-feature mappings (and their weight gradients) on a side stream (measured SLOWER: 1 139 vs 1 159 img/s)
     wgrad_side_stream     SP_WGRAD_SIDE_STREAM   0        weight-gradient launches on a side stream (a parallel graph branch): 1 = all layers, N = maps of <= N pixels - experiment
     reuse_feature_maps    SP_REUSE_FEATURE_MAPS  1        the generator's masked-feature mappings of the G step derived from the D step's forward (same inputs, same weights, other sigma)
+    vgg_pair              SP_VGG_PAIR            1        the VGG-16 pyramid of the NEXT batch's real images rides in the generator step's pass over the fake images (one pass over 2B images; ModelWrapper.train_step(next_images_real=...))
     f16_loss_scale        SP_F16_LOSS_SCALE      65536    static loss scale of the fp16 storage mode (ops.set_compute_dtype(torch.float16))
     vgg_fp8               SP_VGG_FP8             0        BASELINE.json config 5's fp8 slice: VGG-16's wide 3x3 layers on the fp8 MFMA in the no-gradient pass (ops.set_vgg_fp8)
     lib_path              SEMPYR_LIB             (in-tree libsempyr.so)
@@ -52,6 +53,7 @@ class Config:
     fuse_tail: bool = True
     wgrad_side_stream: int = 0
     reuse_feature_maps: bool = True
+    vgg_pair: bool = True
 
     @classmethod
     def from_env(cls) -> "Config":
@@ -62,7 +64,7 @@ class Config:
                    d_pair=_flag("SP_D_PAIR", True), f16_loss_scale=float(os.environ.get("SP_F16_LOSS_SCALE", "65536")),
                    side_features=_flag("SP_SIDE_FEATURES", False),
                    fuse_upsample_bn=_flag("SP_FUSE_UPSAMPLE_BN", True), fuse_tail=_flag("SP_FUSE_TAIL", True),
-                   wgrad_side_stream=int(os.environ.get("SP_WGRAD_SIDE_STREAM", "0")), reuse_feature_maps=_flag("SP_REUSE_FEATURE_MAPS", True))
+                   wgrad_side_stream=int(os.environ.get("SP_WGRAD_SIDE_STREAM", "0")), reuse_feature_maps=_flag("SP_REUSE_FEATURE_MAPS", True), vgg_pair=_flag("SP_VGG_PAIR", True))
 
 
 CFG = Config.from_env()

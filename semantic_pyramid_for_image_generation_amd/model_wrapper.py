@@ -158,13 +158,15 @@ class ModelWrapper(object):
             self.gradient_reducer.join(tag)
 
     # ------------------------------------------------------------------------------------------
-    def _d_phase(self, images_real, labels, labels_f, masks, noise_d):
-        """model_wrapper.py:136-160: forward passes and backward of the discriminator step (everything but Adam)."""
+    def _d_phase(self, images_real, labels, labels_f, masks, noise_d, features_real=None):
+        """model_wrapper.py:136-160: forward passes and backward of the discriminator step (everything but Adam).  features_real: the
+        pyramid of images_real where an earlier generator step has already computed it (_g_rest, next_images_real)."""
         G, D, V = self.generator, self.discriminator, self.vgg16
         G.zero_grad()
         D.zero_grad()
         with torch.no_grad():
-            features_real = V(images_real)
+            if features_real is None:
+                features_real = V(images_real)
             if noise_d is None:
                 noise_d = torch.randn((images_real.shape[0], self.latent_dimensions), dtype=torch.float32, device=images_real.device)
             if hasattr(G, "map_mode"):
@@ -193,8 +195,15 @@ class ModelWrapper(object):
             G.map_mode = "reuse"                      # the masked-feature mappings come from the D step's forward (other sigma only)
         return G(input=noise_g, features=features_real, masks=masks, class_id=labels_f), noise_g
 
-    def _g_rest(self, images_fake, noise_g, labels, masks, features_real, w_rec, w_div):
-        """model_wrapper.py:174-188: D(fake), the three generator losses, backward (everything but Adam)."""
+    def _vgg_pair_ok(self, images_fake, next_images_real) -> bool:
+        return (CFG.vgg_pair and next_images_real is not None and hasattr(self.vgg16, "forward_pair") and ops.vgg_fp8() == 0
+                and next_images_real.is_cuda and tuple(next_images_real.shape) == tuple(images_fake.shape))
+
+    def _g_rest(self, images_fake, noise_g, labels, masks, features_real, w_rec, w_div, next_images_real=None, features_next_out=None):
+        """model_wrapper.py:174-188: D(fake), the three generator losses, backward (everything but Adam).  next_images_real: the real
+        images of the NEXT iteration - their pyramid (model_wrapper.py:141 of that iteration; the network is frozen) is taken in the
+        same pass as the fake images' (VGG16.forward_pair) and kept in self._vgg_ahead; features_next_out: static tensors to copy it
+        into after the backward pass (captured graphs)."""
         D, V = self.discriminator, self.vgg16
         D.zero_grad()
         for p in self._d_params:                               # dead D weight gradients are skipped
@@ -207,7 +216,11 @@ class ModelWrapper(object):
                 loss_div = self.diversity_loss(images_fake, noise_g, weight=w_div)
             else:
                 loss_div = w_div * self.diversity_loss(images_fake, noise_g)
-            features_fake = V(images_fake)
+            features_next = None
+            if self._vgg_pair_ok(images_fake, next_images_real):
+                features_fake, features_next = V.forward_pair(images_fake, next_images_real)
+            else:
+                features_fake = V(images_fake)
             if isinstance(self.semantic_reconstruction_loss, SemanticReconstructionLoss):
                 loss_rec = self.semantic_reconstruction_loss(features_real, features_fake, masks, weight=w_rec)
             else:
@@ -217,16 +230,37 @@ class ModelWrapper(object):
             terms = [loss_g, loss_rec, loss_div]
             torch.autograd.backward(terms, ops.backward_seeds(terms))
             self._finish_backward("g")
+            self._vgg_ahead = None
+            if features_next is not None:
+                if features_next_out is not None:                # (after the backward pass: it still read this iteration's features)
+                    with torch.no_grad():
+                        for dst, src in zip(features_next_out, features_next):
+                            dst.copy_(src)
+                    features_next = features_next_out
+                self._vgg_ahead = (next_images_real, next_images_real._version, features_next)
         finally:
             for p in self._d_params:
                 p.requires_grad_(True)
         return loss_g, loss_rec, loss_div
 
+    def _features_ahead(self, images_real):
+        """The pyramid of images_real if the previous iteration computed it ahead (same tensor object, not written since)."""
+        ahead, self._vgg_ahead = getattr(self, "_vgg_ahead", None), None
+        if ahead is not None and ahead[0] is images_real and ahead[1] == images_real._version:
+            return ahead[2]
+        return None
+
     def train_step(self, images_real: torch.Tensor, labels: torch.Tensor, masks, w_rec: float = 0.1, w_div: float = 0.1,
-                   noise_d: Optional[torch.Tensor] = None, noise_g: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+                   noise_d: Optional[torch.Tensor] = None, noise_g: Optional[torch.Tensor] = None,
+                   next_images_real: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """One iteration of model_wrapper.py:131-190 on tensors already on the device.  ``noise_d`` / ``noise_g``
         replace the two ``torch.randn`` draws (model_wrapper.py:147,168) for parity runs.  Returns the loss
         scalars as device tensors (no host sync).
+
+        ``next_images_real`` (optional): the real images of the NEXT call (the same tensor object must then be passed as its
+        ``images_real``).  The frozen VGG-16 sees them in the pass it makes over this iteration's fake images - one pass over 2B
+        images instead of two over B (config.CFG.vgg_pair) - and the next call finds its pyramid computed.  Results do not change:
+        the network is frozen and in eval mode.
 
         Order of work (results identical to the reference's order): D phase; [D gradients -> side stream]; generator forward of
         the G phase (independent of D); join; Adam(D); rest of the G phase; [G gradients -> side stream]; join; Adam(G)."""
@@ -234,7 +268,8 @@ class ModelWrapper(object):
         # models.py:151,501: five reductions and a float copy per step; our modules pass indices through)
         labels = labels_f = _class_index(labels)
         with profiling.range("D phase"):
-            features_real, loss_d_real, loss_d_fake = self._d_phase(images_real, labels, labels_f, masks, noise_d)
+            features_real, loss_d_real, loss_d_fake = self._d_phase(images_real, labels, labels_f, masks, noise_d,
+                                                                      self._features_ahead(images_real))
             self._start_reduce("d", self._d_params, eager=True)
         with profiling.range("G forward"):
             images_fake, noise_g = self._g_forward(images_real, labels_f, masks, features_real, noise_g)
@@ -242,7 +277,7 @@ class ModelWrapper(object):
             self._join_reduce("d")
             self.discriminator_optimizer.step()
         with profiling.range("G rest"):
-            loss_g, loss_rec, loss_div = self._g_rest(images_fake, noise_g, labels, masks, features_real, w_rec, w_div)
+            loss_g, loss_rec, loss_div = self._g_rest(images_fake, noise_g, labels, masks, features_real, w_rec, w_div, next_images_real)
             self._start_reduce("g", self._g_params, eager=True)
         with profiling.range("Adam(G)"):
             self._join_reduce("g")
@@ -277,22 +312,42 @@ class ModelWrapper(object):
         zdim = (images_real.shape[0], self.latent_dimensions)
         st["noise_d"] = torch.zeros(zdim, dtype=torch.float32, device=images_real.device)
         st["noise_g"] = torch.zeros(zdim, dtype=torch.float32, device=images_real.device)
+        # The pyramid of the real images is computed AHEAD (config.CFG.vgg_pair): the generator-step graph takes the next batch's real
+        # images (st["images_next"]) through the VGG pass it makes over the fake images and leaves their features in st["feats_real"],
+        # which the discriminator-step graph of the next replay reads.  Eager once here, so that the first replay finds them.
+        st["feats_real"] = None
+        if CFG.vgg_pair and hasattr(self.vgg16, "forward_pair") and ops.vgg_fp8() == 0:
+            with torch.no_grad():
+                st["feats_real"] = [f.detach().clone() for f in self.vgg16(st["images"])]
+            st["images_next"] = st["images"].clone()
+            st["resident_ok"] = True           # st["images_next"] holds what st["images"] holds (until a caller streams batches in)
+            st["announced"] = None
+        handed_over = getattr(self, "_vgg_ahead", None)      # the eager iteration in front of this capture announced its successor
+        self._vgg_ahead = None
         self._capturing = True
         try:
             gd = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gd):
                 cls = st["cls"] = _class_index(st["labels"])          # recomputed by every replay of this graph; the other two read it
-                feats, l_real, l_fake = self._d_phase(st["images"], cls, cls, st["masks"], st["noise_d"])
+                feats, l_real, l_fake = self._d_phase(st["images"], cls, cls, st["masks"], st["noise_d"], st["feats_real"])
             st["d_grads"] = [p.grad for p in self._d_params]
             gf = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gf, pool=gd.pool()):
                 fake, _ = self._g_forward(st["images"], cls, st["masks"], feats, st["noise_g"])
             gg = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gg, pool=gd.pool()):
-                l_g, l_rec, l_div = self._g_rest(fake, st["noise_g"], cls, st["masks"], feats, w_rec, w_div)
+                l_g, l_rec, l_div = self._g_rest(fake, st["noise_g"], cls, st["masks"], feats, w_rec, w_div, st.get("images_next"),
+                                                 st["feats_real"])
             st["g_grads"] = [p.grad for p in self._g_params]
         finally:
             self._capturing = False
+            self._vgg_ahead = None
+        if handed_over is not None and st["feats_real"] is not None and handed_over[0]._version == handed_over[1]:
+            with torch.no_grad():                               # ... the first replay finds that batch's pyramid as the eager loop would
+                for dst, src in zip(st["feats_real"], handed_over[2]):
+                    dst.copy_(src)
+            st["announced"] = (handed_over[0], handed_over[1])
+            st["resident_ok"] = False
         st["gd"], st["gf"], st["gg"], st["feats"] = gd, gf, gg, feats
         st["out"] = {"loss_discriminator_real": l_real.detach(), "loss_discriminator_fake": l_fake.detach(),
                      "loss_generator": l_g.detach(), "loss_generator_semantic_reconstruction": l_rec.detach().reshape(()),
@@ -308,10 +363,13 @@ class ModelWrapper(object):
         return tuple(out)
 
     def train_step_graphed(self, images_real: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None, masks=None,
-                           noise_d: Optional[torch.Tensor] = None, noise_g: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+                           noise_d: Optional[torch.Tensor] = None, noise_g: Optional[torch.Tensor] = None,
+                           next_images_real: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """train_step() through the captured graphs (capture_graphs() first).  images / labels / masks: new batch to copy into
-        the graphs' static inputs, or None to reuse the resident one.  The returned tensors are the graphs' static outputs:
-        they are overwritten by the next call."""
+        the graphs' static inputs, or None to reuse the resident one.  next_images_real: as in train_step() - the next call's real
+        images, whose VGG pyramid this call computes ahead; without it (and outside the resident mode) the next call computes its
+        pyramid eagerly in front of its first graph.  The returned tensors are the graphs' static outputs: they are overwritten by
+        the next call."""
         st = self._graph_state
         if st is None or st.get("flat_ptrs") != self._flat_ptrs():
             self._graph_state = None
@@ -321,8 +379,24 @@ class ModelWrapper(object):
             st["noise_d"].normal_()
         else:
             st["noise_d"].copy_(noise_d)
+        ahead = st.get("feats_real") is not None
+        feats_ok = ahead and st["resident_ok"]
         if images_real is not None and images_real is not st["images"]:
             st["images"].copy_(images_real, non_blocking=True)
+            if ahead:
+                ann = st["announced"]
+                feats_ok = ann is not None and ann[0] is images_real and ann[1] == images_real._version
+                st["resident_ok"] = False
+        if ahead:
+            st["announced"] = None
+            if next_images_real is not None:
+                st["images_next"].copy_(next_images_real, non_blocking=True)
+                st["resident_ok"] = False
+                st["announced"] = (next_images_real, next_images_real._version)
+            if not feats_ok:                                    # nobody computed this batch's pyramid ahead: now, eagerly
+                with torch.no_grad():
+                    for dst, src in zip(st["feats_real"], self.vgg16(st["images"])):
+                        dst.copy_(src)
         if labels is not None and labels is not st["labels"]:
             st["labels"].copy_(labels, non_blocking=True)
         if masks is not None and masks is not st["masks"]:
@@ -360,13 +434,15 @@ class ModelWrapper(object):
         return (tuple(images_real.shape), images_real.dtype, tuple(labels.shape), labels.dtype,
                 tuple((tuple(m.shape), m.dtype) for m in masks), str(images_real.device))
 
-    def _train_iteration(self, images_real, labels, masks, w_rec: float, w_div: float) -> Dict[str, torch.Tensor]:
+    def _train_iteration(self, images_real, labels, masks, w_rec: float, w_div: float, next_images_real=None) -> Dict[str, torch.Tensor]:
         """One iteration of train(): the first ``graph_after_iterations`` batches (config.CFG.graph_after, default 3; 0 = never)
         run eagerly, then - the batch shapes being static, as with the reference's drop_last loader (main.py:80-88) - the step
         is captured once and every further batch of the same shapes REPLAYS the three HIP graphs (its tensors are copied into
         the graphs' static inputs).  A batch of other shapes, or any failure to capture, runs eagerly.  Replay and eager
         launches execute the same kernels in the same order on the same RNG stream: the logged metrics are identical
-        (tests/test_gpu_frontdoor.py)."""
+        (tests/test_gpu_frontdoor.py).  An iteration without an announced successor (next_images_real is None: an epoch's last) runs
+        eagerly even after the capture: the captured generator-step graph always takes the NEXT batch's VGG pyramid in its pass
+        over the fake images."""
         after = self.graph_after_iterations
         sig = self._batch_signature(images_real, labels, masks)
         st = self._graph_state
@@ -379,8 +455,17 @@ class ModelWrapper(object):
             st = self._graph_state = None                       # gradient buffers re-allocated: eager steps, then a fresh capture
             self._eager_run = 0
         if st is not None and st.get("sig") == sig and st.get("w") == (w_rec, w_div):
-            return self.train_step_graphed(images_real, labels, masks)
-        out = self.train_step(images_real, labels, masks, w_rec=w_rec, w_div=w_div)
+            # the captured generator-step graph takes the next batch's VGG pyramid in its pass over the fake images; an iteration
+            # without a successor (an epoch's last) runs eagerly instead - the same kernels as the eager loop, one iteration per epoch
+            if st.get("feats_real") is None or next_images_real is not None:
+                return self.train_step_graphed(images_real, labels, masks, next_images_real=next_images_real)
+            ann = st.get("announced")
+            if ann is not None and ann[0] is images_real and ann[1] == images_real._version:
+                self._vgg_ahead = (images_real, ann[1], st["feats_real"])       # computed ahead by the last replay
+            st["announced"] = None
+        out = self.train_step(images_real, labels, masks, w_rec=w_rec, w_div=w_div, next_images_real=next_images_real)
+        if st is not None and st.get("sig") == sig:
+            return out                                          # (an eager iteration under a valid capture: nothing to re-capture)
         if after and after > 0 and images_real.is_cuda and not self._graph_failed:
             self._eager_run = self._eager_run + 1 if sig == self._eager_sig else 1
             self._eager_sig = sig
@@ -412,6 +497,25 @@ class ModelWrapper(object):
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=red.group)
         return bool(int(flag.item()))
 
+    def _device_batches(self, device):
+        """One pass over the training loader: (images, labels, masks, next batch's images or None), every batch moved to the device when
+        it is FETCHED - one batch ahead where config.CFG.vgg_pair is on, so that an iteration can hand the next one's real images to the
+        frozen VGG-16 together with its own fake images (train_step: next_images_real).  The tensors are those of model_wrapper.py:
+        133-135; a next batch of another shape (a last, smaller batch) is simply not announced."""
+        def fetch(it):
+            batch = next(it, None)
+            if batch is None:
+                return None
+            images_real, labels, masks = batch
+            return images_real.detach().to(device), labels.to(device), [m.detach().to(device) for m in masks]
+        it = iter(self.training_dataset)
+        cur = fetch(it)
+        while cur is not None:
+            nxt = fetch(it) if CFG.vgg_pair else None
+            ahead = nxt[0] if nxt is not None and nxt[0].shape == cur[0].shape else None
+            yield cur[0], cur[1], cur[2], ahead
+            cur = nxt if CFG.vgg_pair else fetch(it)
+
     def train(self, epochs: int = 20, validate_after_n_iterations: int = 100000, device: str = 'cuda',
               save_model_after_n_epochs: int = 1, w_rec: float = 0.1, w_div: float = 0.1) -> None:
         """model_wrapper.py:93-228."""
@@ -436,12 +540,9 @@ class ModelWrapper(object):
             self.generator.train()
             self.discriminator.train()
             self.vgg16.eval()
-            for images_real, labels, masks in self.training_dataset:
+            for images_real, labels, masks, next_images_real in self._device_batches(device):
                 self.progress_bar.update(n=images_real.shape[0])
-                images_real = images_real.detach().to(device)
-                labels = labels.to(device)
-                masks = [m.detach().to(device) for m in masks]
-                out = self._train_iteration(images_real, labels, masks, w_rec, w_div)
+                out = self._train_iteration(images_real, labels, masks, w_rec, w_div, next_images_real)
                 vals = torch.stack([out[n].float().reshape(()) for n in names]).tolist()      # the single host sync
                 l_div, l_rec, l_g, l_df, l_dr = vals
                 self.progress_bar.set_description(

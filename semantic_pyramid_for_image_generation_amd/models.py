@@ -594,15 +594,22 @@ class _VGGPyramidFn(torch.autograd.Function):
     into each dgrad epilogue (mask_src) and into the max-pool backward."""
 
     @staticmethod
-    def forward(ctx, img, packs, dtype):
+    def forward(ctx, img, packs, dtype, img_b=None):
+        """img_b (a second batch that needs NO gradient, e.g. the next iteration's real images): the pyramid runs ONCE over [img | img_b]
+        - the 16 x 16 / 32 x 32 stages fill 31 - 62 % of the CUs at batch 20 - and returns the seven features of img followed by the
+        seven of img_b; the backward walks only the first img.shape[0] images of every saved tensor (a prefix: same base addresses)."""
         import ctypes
         Lb = ops.L
         dev = img.device
-        n = img.shape[0]
+        n_grad = img.shape[0]
+        n = n_grad + (img_b.shape[0] if img_b is not None else 0)
         scale = tuple(1.0 / s for s in _IMAGENET_STD)
         shift = tuple(-m / s for m, s in zip(_IMAGENET_MEAN, _IMAGENET_STD))
         with torch.no_grad():
-            x = ops.ingest_image(img.detach(), dtype, scale, shift)
+            if img_b is None:
+                x = ops.ingest_image(img.detach(), dtype, scale, shift)
+            else:
+                x = ops.ingest_image_pair(img, img_b, dtype, scale, shift)
         acts = [x]                 # conv inputs / pool inputs, in order
         feats = []
         h = w = img.shape[2]
@@ -697,7 +704,10 @@ class _VGGPyramidFn(torch.autograd.Function):
 
         def lin(inp, pk, nout, act):
             out = torch.empty((n, nout), dtype=dtype, device=dev)
-            ops.linear_launch(inp, pk["fwd"].data_ptr(), pk["kp"], pk["bias"], None, out, n, inp.shape[1], nout, act)
+            for lo in range(0, n, n_grad):                       # per group: the split-K MFMA form takes up to 32 rows
+                rows = min(n_grad, n - lo)
+                ops.linear_launch(inp[lo:lo + rows], pk["fwd"].data_ptr(), pk["kp"], pk["bias"], None, out[lo:lo + rows], rows, inp.shape[1],
+                                  nout, act)
             return out
         h1 = lin(flat, fcs[0], 4096, ACT_RELU)
         # tap 5 is POST-ReLU: torchvision's classifier[4] is ReLU(inplace=True) and overwrites the tensor appended at
@@ -713,7 +723,12 @@ class _VGGPyramidFn(torch.autograd.Function):
         ctx.img_meta = (img.shape, img.dtype)
         ctx.save_for_backward(*acts, p7, h1, h2)
         ctx.n_acts = len(acts)
-        return tuple(feats)
+        ctx.n_grad = n_grad
+        if img_b is None:
+            return tuple(feats)
+        second = tuple(f[n_grad:] for f in feats)                # batch-outermost layouts: both halves are dense
+        ctx.mark_non_differentiable(*second)
+        return tuple(f[:n_grad] for f in feats) + second
 
     @staticmethod
     def backward(ctx, *dfeats):
@@ -723,7 +738,9 @@ class _VGGPyramidFn(torch.autograd.Function):
         p7, h1, h2 = saved[ctx.n_acts:]
         dtype, packs = ctx.dtype, ctx.packs
         dev = h1.device
-        n = h1.shape[0]
+        n = ctx.n_grad                    # (two-group pass: the first n images of every saved tensor)
+        dfeats = dfeats[:7]
+        h1, h2 = h1[:n], h2[:n]
         fcs = packs["fc"]
         sd = ops.sp_dtype(dtype)
 
@@ -785,7 +802,7 @@ class _VGGPyramidFn(torch.autograd.Function):
                                 g.shape[1], pk["cin"], cin_p, 3, ACT_NONE, dtype, family="dgrad")
                 g = dx
         if g is None:
-            return None, None, None
+            return None, None, None, None
         shape, src_dtype = ctx.img_meta
         dimg = ops.nhwc_empty(n, 3, shape[2], shape[3], dtype, dev)
         import ctypes
@@ -794,7 +811,7 @@ class _VGGPyramidFn(torch.autograd.Function):
                 sd, ops.stream())
         if dimg.dtype != src_dtype:
             dimg = dimg.to(src_dtype)
-        return dimg, None, None
+        return dimg, None, None, None
 
 
 class VGG16(nn.Module):
@@ -871,3 +888,19 @@ class VGG16(nn.Module):
         if self.return_output:
             return feats[-1]
         return list(feats)
+
+    def forward_pair(self, input: torch.Tensor, input_no_grad: torch.Tensor):
+        """The pyramid of two batches in ONE pass: `input` (may need its image gradient - the generator step's fake images,
+        model_wrapper.py:179) and `input_no_grad` (a batch of real images, model_wrapper.py:141).  Returns (features of input, features of
+        input_no_grad), each as forward() would - the network is frozen and in eval mode, so the two results do not depend on each
+        other; only the tile counts of the deep stages do (80 -> 160 work items on 256 CUs at batch 20)."""
+        if self.training:
+            raise ops.L.SempyrError("VGG16 is used frozen in eval mode (model_wrapper.py:114); call .eval()")
+        ops.require_gpu(input)
+        if input.shape[1:] != input_no_grad.shape[1:] or input.shape[1] != 3:
+            raise ops.L.SempyrError("VGG16.forward_pair: two RGB batches of one image size are expected")
+        if ops.vgg_fp8() > 0:
+            raise ops.L.SempyrError("VGG16.forward_pair: the fp8 slice (ops.set_vgg_fp8) runs in the no-gradient pass only")
+        dt = ops.compute_dtype()
+        feats = _VGGPyramidFn.apply(input, self._packed(dt, input.device), dt, input_no_grad.detach())
+        return list(feats[:7]), [f.detach() for f in feats[7:]]

@@ -1467,9 +1467,10 @@ def ingest_image(img, dtype, scale3=None, shift3=None):
     return _IngestFn.apply(img, dtype, scale3, shift3)
 
 
-def ingest_image_pair(img_a: torch.Tensor, img_b: torch.Tensor, dtype) -> torch.Tensor:
-    """Two image batches (any strides; fp32 or compute dtype) -> ONE padded NHWC batch [a | b] (no autograd: the discriminator
-    step needs no image gradients, model_wrapper.py:150-160)."""
+def ingest_image_pair(img_a: torch.Tensor, img_b: torch.Tensor, dtype, scale3=None, shift3=None) -> torch.Tensor:
+    """Two image batches (any strides; fp32 or compute dtype) -> ONE padded NHWC batch [a | b], optional per-channel affine (no
+    autograd of its own: the discriminator step needs no image gradients, model_wrapper.py:150-160; the VGG pyramid's two-group pass
+    takes the image gradient of group a in its own backward)."""
     with torch.no_grad():
         require_gpu(img_a)
         na, c, h, w = img_a.shape
@@ -1477,10 +1478,13 @@ def ingest_image_pair(img_a: torch.Tensor, img_b: torch.Tensor, dtype) -> torch.
         cp = pad_channels(c, dtype)
         y = nhwc_empty(na + nb, cp, h, w, dtype, img_a.device)
         esz = y.element_size()
+        sc = (ctypes.c_float * 3)(*scale3) if scale3 is not None else None
+        sf = (ctypes.c_float * 3)(*shift3) if shift3 is not None else None
         for img, off in ((img_a.detach(), 0), (img_b.detach(), na)):
             sn, scs, sh, sw = img.stride()
             L.call("sp_ingest_image", ptr(img), sp_dtype(img.dtype), sn, scs, sh, sw, ctypes.c_void_p(y.data_ptr() + off * h * w * cp * esz),
-                   img.shape[0], c, h, w, cp, None, None, sp_dtype(dtype), stream())
+                   img.shape[0], c, h, w, cp, ctypes.cast(sc, ctypes.c_void_p) if sc is not None else None,
+                   ctypes.cast(sf, ctypes.c_void_p) if sf is not None else None, sp_dtype(dtype), stream())
     return y
 
 

@@ -258,3 +258,84 @@ def test_second_generator_forward_reuses_the_feature_mappings(dtype, tol):
             assert torch.equal(b0[n], b1[n]), n           # the power iterations see the weights only
         elif b0[n].dtype.is_floating_point:                # BatchNorm running statistics follow the activations
             assert torch.allclose(b0[n], b1[n], rtol=1e-5 if dtype == torch.float32 else 2e-2, atol=1e-7 if dtype == torch.float32 else 2e-3), n
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
+def test_vgg_pyramid_of_two_batches_in_one_pass(dtype, tol):
+    """VGG16.forward_pair (ModelWrapper: the next iteration's real images ride in the generator step's pass over the fake images,
+    model_wrapper.py:141,179): the features of both batches and the image gradient of the first equal two separate forwards (the
+    network is frozen, eval mode; only kernel routes / tile counts differ - fp32: summation order)."""
+    import semantic_pyramid_for_image_generation_amd as spm
+    ops.set_compute_dtype(dtype)
+    try:
+        V = spm.VGG16()
+        _, _, Vsd = gu.synth_states({"cf": 4, "seed": 7})
+        V.load_state_dict(Vsd)
+        V.cuda().eval()
+        g = torch.Generator().manual_seed(3)
+        a = (torch.rand(3, 3, 256, 256, generator=g) * 2 - 1).cuda()
+        b = (torch.rand(3, 3, 256, 256, generator=g) * 2 - 1).cuda()
+        seeds = None
+        a1 = a.clone().requires_grad_(True)
+        fa = V(a1)
+        with torch.no_grad():
+            fb = V(b)
+        seeds = [torch.randn(f.shape, generator=torch.Generator().manual_seed(10 + i)).cuda().to(f.dtype) for i, f in enumerate(fa)]
+        torch.autograd.backward(fa, seeds)
+        a2 = a.clone().requires_grad_(True)
+        pa, pb = V.forward_pair(a2, b)
+        assert all(not f.requires_grad for f in pb)
+        torch.autograd.backward(pa, seeds)
+        for i, (x, y) in enumerate(zip(pa + pb, fa + fb)):
+            assert x.shape == y.shape
+            err = float((x.float() - y.float()).norm() / y.float().norm().clamp_min(1e-12))
+            assert err <= tol, ("feature", i, err)
+        err = float((a2.grad - a1.grad).norm() / a1.grad.norm())
+        assert err <= 2 * tol, ("image gradient", err)
+    finally:
+        ops.set_compute_dtype(torch.float32)
+
+
+def test_train_step_with_the_next_batch_announced_matches_plain_steps():
+    """ModelWrapper.train_step(next_images_real=...) (config.CFG.vgg_pair): three iterations over two alternating batches, each
+    announcing the next one's real images, against the same iterations without the announcement - fp32, same RNG stream: losses and
+    pixels agree to summation order; and the pyramid computed ahead is really the one used (the VGG runs twice per step, not three times)."""
+    import semantic_pyramid_for_image_generation_amd as spm
+    from semantic_pyramid_for_image_generation_amd import models
+    ops.set_compute_dtype(torch.float32)
+    meta = {"cf": 4, "seed": 7}
+    Gsd, Dsd, Vsd = gu.synth_states(meta)
+    batches = [(im.cuda(), lb.cuda(), [m.cuda() for m in ms]) for im, lb, ms in gu.golden_batches(2, 5)[:2]]
+    runs = []
+    for announce in (False, True):
+        G, D, V = spm.Generator(channels_factor=4), spm.Discriminator(channel_factor=4), spm.VGG16()
+        G.load_state_dict(Gsd); D.load_state_dict(Dsd); V.load_state_dict(Vsd)
+        G.cuda().train(); D.cuda().train(); V.cuda().eval()
+        mw = spm.ModelWrapper(generator=G, discriminator=D, vgg16=V, training_dataset=None, validation_dataset=None,
+                              generator_optimizer=spm.optim.Adam(G.parameters(), lr=1e-4), discriminator_optimizer=spm.optim.Adam(D.parameters(), lr=1e-4),
+                              save_data_path=None)
+        calls = [0]
+        plain, pair = models.VGG16.forward, models.VGG16.forward_pair
+        def count(self, *a, _f=None, **k):
+            calls[0] += 1
+            return _f(self, *a, **k)
+        models.VGG16.forward = lambda self, *a, **k: count(self, *a, _f=plain, **k)
+        models.VGG16.forward_pair = lambda self, *a, **k: count(self, *a, _f=pair, **k)
+        try:
+            torch.manual_seed(21)
+            outs = []
+            for t in range(3):
+                im, lb, ms = batches[t % 2]
+                nxt = batches[(t + 1) % 2][0] if announce else None
+                out = mw.train_step(im, lb, ms, next_images_real=nxt)
+                outs.append({k: v.detach().float().clone() for k, v in out.items()})
+        finally:
+            models.VGG16.forward, models.VGG16.forward_pair = plain, pair
+        runs.append((outs, calls[0]))
+    (plain_outs, plain_calls), (pair_outs, pair_calls) = runs
+    assert plain_calls == 6 and pair_calls == 4, (plain_calls, pair_calls)       # V(real) + V(fake) per step | V(real_0), then one pass per step
+    for a, b in zip(plain_outs, pair_outs):
+        for k in a:
+            if k.startswith("loss"):
+                assert float(b[k]) == pytest.approx(float(a[k]), rel=2e-4, abs=1e-6), k
+        assert float((a["images_fake"] - b["images_fake"]).abs().max()) <= 2e-4

@@ -228,12 +228,16 @@ def _eager_vs_graphed(dtype, tag):
         images, labels, masks = next(iter(gu.golden_batches(meta["batch_size"], meta["seed"])))
         images, labels, masks = images.cuda(), labels.cuda(), [m.cuda() for m in masks]
         torch.manual_seed(11)
-        mw.train_step(images, labels, masks)                     # warm-up step (eager in both runs)
+        # (every step announces the next one's real images - here the same batch -, as ModelWrapper.train() does: the captured
+        # generator-step graph always takes the VGG pyramid of the fake images and of the next batch in ONE pass, and "the same
+        # kernels in the same order" needs the eager steps to do so too)
+        mw.train_step(images, labels, masks, next_images_real=images)                     # warm-up step (eager in both runs)
         if graphed:
             mw.capture_graphs(images, labels, masks)
         out = None
         for _ in range(2):
-            out = mw.train_step_graphed(images, labels, masks) if graphed else mw.train_step(images, labels, masks)
+            out = (mw.train_step_graphed(images, labels, masks, next_images_real=images) if graphed
+                   else mw.train_step(images, labels, masks, next_images_real=images))
         rec = {k: float(v) for k, v in out.items() if k.startswith("loss")}
         rec["pixels"] = out["images_fake"].detach().float().clone()
         rec["G"] = {k: v.detach().clone() for k, v in G.state_dict().items()}
