@@ -5,7 +5,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import semantic_pyramid_for_image_generation_amd as sp
 from semantic_pyramid_for_image_generation_amd import ops, params
-ops.set_compute_dtype(torch.bfloat16)
+DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "f32": torch.float32}[sys.argv[1] if len(sys.argv) > 1 else "bf16"]
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+ops.set_compute_dtype(DT)
 V = sp.VGG16()
 V.load_state_dict(params.synth_state_dict(V.state_dict(), 2))
 V.cuda().eval()
@@ -22,13 +24,16 @@ def timeit(fn, reps=10):
         e1.record(); torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / reps * 1e3)
     return best
-img20 = torch.rand(20, 3, 256, 256, device="cuda") * 2 - 1
-img40 = torch.rand(40, 3, 256, 256, device="cuda") * 2 - 1
+img20 = torch.rand(B, 3, 256, 256, device="cuda") * 2 - 1
+img40 = torch.rand(2 * B, 3, 256, 256, device="cuda") * 2 - 1
+imgb = torch.rand(B, 3, 256, 256, device="cuda") * 2 - 1
 def nograd20():
     with torch.no_grad(): V(img20)
 def grad20():
     V(img20.clone().requires_grad_(True))
 def grad40():
     V(img40.clone().requires_grad_(True))
-a, b, c = timeit(nograd20), timeit(grad20), timeit(grad40)
-print("no-grad 20: %.0f us   grad 20: %.0f us   sum %.0f us   |   grad 40: %.0f us   -> saves %.0f us per step" % (a, b, a + b, c, a + b - c))
+def pair():
+    V.forward_pair(img20.clone().requires_grad_(True), imgb)
+a, b, c, d = timeit(nograd20), timeit(grad20), timeit(grad40), timeit(pair)
+print("%s B=%d: no-grad B: %.0f us   grad B: %.0f us   sum %.0f us   |   grad 2B: %.0f us   forward_pair: %.0f us   -> saves %.0f us per step" % (sys.argv[1:] , B, a, b, a + b, c, d, a + b - d))

@@ -196,8 +196,15 @@ class ModelWrapper(object):
         return G(input=noise_g, features=features_real, masks=masks, class_id=labels_f), noise_g
 
     def _vgg_pair_ok(self, images_fake, next_images_real) -> bool:
-        return (CFG.vgg_pair and next_images_real is not None and hasattr(self.vgg16, "forward_pair") and ops.vgg_fp8() == 0
-                and next_images_real.is_cuda and tuple(next_images_real.shape) == tuple(images_fake.shape))
+        """One VGG pass over [fake | next real] pays where a batch alone leaves CUs idle in the pyramid's deep stages (batch 20 at
+        256 x 256: 80 work items on 256 CUs in the 16 x 16 stage, 320 in the 32 x 32 stage): same box, bf16 15.73 -> 15.58 ms, fp32
+        103.5 -> 102.2 ms per step; at batch 32 the stages are full already and the pass costs 0.7 % (the second half cannot pool in
+        the convolution epilogue) - so: up to 24 images of 256 x 256 (n x (H / 64) x (W / 64) <= 384)."""
+        if not (CFG.vgg_pair and next_images_real is not None and hasattr(self.vgg16, "forward_pair") and ops.vgg_fp8() == 0
+                and next_images_real.is_cuda and tuple(next_images_real.shape) == tuple(images_fake.shape)):
+            return False
+        n, _, h, w = images_fake.shape
+        return n * (h // 64) * (w // 64) <= 384
 
     def _g_rest(self, images_fake, noise_g, labels, masks, features_real, w_rec, w_div, next_images_real=None, features_next_out=None):
         """model_wrapper.py:174-188: D(fake), the three generator losses, backward (everything but Adam).  next_images_real: the real
@@ -316,12 +323,13 @@ class ModelWrapper(object):
         # images (st["images_next"]) through the VGG pass it makes over the fake images and leaves their features in st["feats_real"],
         # which the discriminator-step graph of the next replay reads.  Eager once here, so that the first replay finds them.
         st["feats_real"] = None
-        if CFG.vgg_pair and hasattr(self.vgg16, "forward_pair") and ops.vgg_fp8() == 0:
+        if self._vgg_pair_ok(st["images"], st["images"]):
             with torch.no_grad():
                 st["feats_real"] = [f.detach().clone() for f in self.vgg16(st["images"])]
             st["images_next"] = st["images"].clone()
-            st["resident_ok"] = True           # st["images_next"] holds what st["images"] holds (until a caller streams batches in)
-            st["announced"] = None
+            st["next_is_resident"] = True      # st["images_next"] holds what st["images"] holds (until a caller streams batches in)
+            st["resident_ok"] = True           # st["feats_real"] is the pyramid of what st["images"] holds
+            st["announced"] = None             # (tensor, version) whose pyramid st["feats_real"] holds, if a caller announced it
         handed_over = getattr(self, "_vgg_ahead", None)      # the eager iteration in front of this capture announced its successor
         self._vgg_ahead = None
         self._capturing = True
@@ -347,7 +355,7 @@ class ModelWrapper(object):
                 for dst, src in zip(st["feats_real"], handed_over[2]):
                     dst.copy_(src)
             st["announced"] = (handed_over[0], handed_over[1])
-            st["resident_ok"] = False
+            st["resident_ok"] = handed_over[0] is images_real       # (the resident batch announced as its own successor: bench.py)
         st["gd"], st["gf"], st["gg"], st["feats"] = gd, gf, gg, feats
         st["out"] = {"loss_discriminator_real": l_real.detach(), "loss_discriminator_fake": l_fake.detach(),
                      "loss_generator": l_g.detach(), "loss_generator_semantic_reconstruction": l_rec.detach().reshape(()),
@@ -380,19 +388,22 @@ class ModelWrapper(object):
         else:
             st["noise_d"].copy_(noise_d)
         ahead = st.get("feats_real") is not None
-        feats_ok = ahead and st["resident_ok"]
+        feats_ok = ahead and st["resident_ok"]                  # resident batch: its pyramid is what the last replay left behind
         if images_real is not None and images_real is not st["images"]:
             st["images"].copy_(images_real, non_blocking=True)
             if ahead:
                 ann = st["announced"]
                 feats_ok = ann is not None and ann[0] is images_real and ann[1] == images_real._version
-                st["resident_ok"] = False
+                st["next_is_resident"] = False
         if ahead:
-            st["announced"] = None
             if next_images_real is not None:
                 st["images_next"].copy_(next_images_real, non_blocking=True)
-                st["resident_ok"] = False
+                st["next_is_resident"] = False
                 st["announced"] = (next_images_real, next_images_real._version)
+            else:
+                st["announced"] = None
+            # after this call st["feats_real"] holds the pyramid of st["images_next"]: the resident batch's only while both buffers agree
+            st["resident_ok"] = st["next_is_resident"]
             if not feats_ok:                                    # nobody computed this batch's pyramid ahead: now, eagerly
                 with torch.no_grad():
                     for dst, src in zip(st["feats_real"], self.vgg16(st["images"])):
