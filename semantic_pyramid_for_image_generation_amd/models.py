@@ -691,6 +691,26 @@ class _VGGPyramidFn(torch.autograd.Function):
                     ops.conv_launch(x, pk["fwd"].data_ptr(), pk["bias"], y, None, None, None, 0.0, n, h, w, x.shape[1], v, v, 3, ACT_RELU,
                                     dtype, pool2=2)
                     skip_pool = True
+                elif (n > n_grad and _FUSE_POOL2 and v <= 128 and k + 1 < len(_VGG_CFG) and _VGG_CFG[k + 1] == "M"
+                      and ops.conv_pool2_ok(h, w, v, 3)):
+                    # two-group pass, last convolution of the first two stages (64 / 128 channels at 256^2 / 128^2: whole rounds of work
+                    # items at either batch size, so one launch over 2B images gains nothing there): the group WITH gradient keeps its
+                    # unpooled output for the backward pass, the group without takes ReLU + MaxPool in the convolution's epilogue -
+                    # its full-resolution tensor (168 / 84 MB) is neither written nor read back by a pooling pass
+                    yf = ops.nhwc_empty(n_grad, v, h, w, dtype, dev)
+                    ops.conv_launch(x[:n_grad], pk["fwd"].data_ptr(), pk["bias"], yf, None, None, None, 0.0, n_grad, h, w, x.shape[1], v, v, 3,
+                                    ACT_RELU, dtype)
+                    trace.append(("conv", len(acts) - 1, pk))
+                    acts.append(yf)
+                    y = ops.nhwc_empty(n, v, h // 2, w // 2, dtype, dev)
+                    Lb.call("sp_maxpool2_fwd", ops.ptr(yf), ops.ptr(y), n_grad, h, w, v, 0, ops.sp_dtype(dtype), ops.stream())
+                    trace.append(("pool", len(acts) - 1))
+                    ops.conv_launch(x[n_grad:], pk["fwd"].data_ptr(), pk["bias"], y[n_grad:], None, None, None, 0.0, n - n_grad, h, w, x.shape[1],
+                                    v, v, 3, ACT_RELU, dtype, pool2=2)
+                    skip_pool = True
+                    x = y
+                    acts.append(x)
+                    continue
                 else:
                     y = ops.nhwc_empty(n, v, h, w, dtype, dev)
                     ops.conv_launch(x, pk["fwd"].data_ptr(), pk["bias"], y, None, None, None, 0.0, n, h, w, x.shape[1], v, v, 3, ACT_RELU, dtype)
