@@ -92,6 +92,8 @@ class ModelWrapper(object):
         self._graph_state = None
         self.graph_after_iterations = CFG.graph_after       # train(): eager iterations before the step is captured (0 = never)
         self._eager_run, self._eager_sig, self._graph_failed = 0, None, False
+        # (real images tensor, its ._version, its VGG pyramid) where the previous iteration computed it ahead (train_step: next_images_real)
+        self._vgg_ahead = None
         self._capturing = False
         self._fired = set()
         self.iterations = 0
@@ -252,7 +254,7 @@ class ModelWrapper(object):
 
     def _features_ahead(self, images_real):
         """The pyramid of images_real if the previous iteration computed it ahead (same tensor object, not written since)."""
-        ahead, self._vgg_ahead = getattr(self, "_vgg_ahead", None), None
+        ahead, self._vgg_ahead = self._vgg_ahead, None
         if ahead is not None and ahead[0] is images_real and ahead[1] == images_real._version:
             return ahead[2]
         return None
@@ -330,7 +332,7 @@ class ModelWrapper(object):
             st["next_is_resident"] = True      # st["images_next"] holds what st["images"] holds (until a caller streams batches in)
             st["resident_ok"] = True           # st["feats_real"] is the pyramid of what st["images"] holds
             st["announced"] = None             # (tensor, version) whose pyramid st["feats_real"] holds, if a caller announced it
-        handed_over = getattr(self, "_vgg_ahead", None)      # the eager iteration in front of this capture announced its successor
+        handed_over = self._vgg_ahead      # the eager iteration in front of this capture announced its successor
         self._vgg_ahead = None
         self._capturing = True
         try:

@@ -146,3 +146,28 @@ def test_device_mask_shapes_are_the_four_kinds():
     mean = [sum(f) / len(f) for f in fill]
     # rectangle: its box; inscribed ellipse: pi / 4; triangle: 1 / 2; circle of diameter min(h, w): pi / 4 of the SMALLER square
     assert mean[0] == 1.0 and 0.4 < mean[1] < 0.8 and 0.4 < mean[2] < 0.6 and 0.72 < mean[3] < 0.88, mean
+
+
+def test_train_loop_fetches_one_batch_ahead():
+    """ModelWrapper._device_batches (the loop of model_wrapper.py:131-135 with the next iteration's real images announced to the
+    current one - config.CFG.vgg_pair): every batch exactly once and in order, the announced tensor IS the next iteration's images
+    tensor, a last batch of another shape is not announced, and with the switch off nothing is fetched ahead."""
+    import types
+    from semantic_pyramid_for_image_generation_amd import model_wrapper as mwm
+
+    def batch(i, n):
+        return torch.full((n, 3, 8, 8), float(i)), torch.zeros(n, 5), [torch.ones(n, 1, 4, 4)]
+    loader = [batch(0, 4), batch(1, 4), batch(2, 4), batch(3, 2)]
+    stub = types.SimpleNamespace(training_dataset=loader)
+    old = mwm.CFG.vgg_pair
+    try:
+        mwm.CFG.vgg_pair = True
+        got = list(mwm.ModelWrapper._device_batches(stub, "cpu"))
+        assert [float(g[0].flatten()[0]) for g in got] == [0.0, 1.0, 2.0, 3.0]
+        assert got[0][3] is got[1][0] and got[1][3] is got[2][0]
+        assert got[2][3] is None and got[3][3] is None          # other shape / no successor
+        mwm.CFG.vgg_pair = False
+        got = list(mwm.ModelWrapper._device_batches(stub, "cpu"))
+        assert [float(g[0].flatten()[0]) for g in got] == [0.0, 1.0, 2.0, 3.0] and all(g[3] is None for g in got)
+    finally:
+        mwm.CFG.vgg_pair = old
