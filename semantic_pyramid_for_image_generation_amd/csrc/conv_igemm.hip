@@ -1235,34 +1235,38 @@ __global__ __launch_bounds__(256) void conv1x1_splitk_kernel(sp_conv_params p) {
         const int row = co0 + arow + i * 4;
         wr[i] = wg + (long)(row < p.cout ? row : p.cout - 1) * CIN + g * 8;   // rows past Cout are computed on a copy and never stored
     }
-    uint4 a[KMAX][4], b[KMAX][2];
-    static_for<KMAX>([&](auto uc) {
-        constexpr int u = decltype(uc)::value;
-        const int m = m0 + u;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[u][i] = make_uint4(0, 0, 0, 0);
-        b[u][0] = make_uint4(0, 0, 0, 0);
-        b[u][1] = make_uint4(0, 0, 0, 0);
-        if (u < cnt && m * 32 + g * 8 < CIN) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[u][i] = *reinterpret_cast<const uint4*>(wr[i] + m * 32);
-            b[u][0] = *reinterpret_cast<const uint4*>(x0 + m * 32);
-            b[u][1] = *reinterpret_cast<const uint4*>(x1 + m * 32);
-        }
-    });
     f32x4_t acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { acc[i][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
-    static_for<KMAX>([&](auto uc) {
-        constexpr int u = decltype(uc)::value;
-        if (u < cnt) {
+    // a wave's K-steps in chunks of KMAX (one chunk for Cin <= 32 * 4 * KMAX; Cin > 1024 - channel_factor 0.5's 1536-channel input
+    // gradient on its 2 x 2 map - walks two or more, in a fixed order)
+    for (int c0 = 0; c0 < cnt; c0 += KMAX) {
+        uint4 a[KMAX][4], b[KMAX][2];
+        static_for<KMAX>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            const int m = m0 + c0 + u;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[u][i]), __builtin_bit_cast(bf16x8_t, b[u][0]), acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[u][i]), __builtin_bit_cast(bf16x8_t, b[u][1]), acc[i][1], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) a[u][i] = make_uint4(0, 0, 0, 0);
+            b[u][0] = make_uint4(0, 0, 0, 0);
+            b[u][1] = make_uint4(0, 0, 0, 0);
+            if (c0 + u < cnt && m * 32 + g * 8 < CIN) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[u][i] = *reinterpret_cast<const uint4*>(wr[i] + m * 32);
+                b[u][0] = *reinterpret_cast<const uint4*>(x0 + m * 32);
+                b[u][1] = *reinterpret_cast<const uint4*>(x1 + m * 32);
             }
-        }
-    });
+        });
+        static_for<KMAX>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            if (c0 + u < cnt) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[u][i]), __builtin_bit_cast(bf16x8_t, b[u][0]), acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[u][i]), __builtin_bit_cast(bf16x8_t, b[u][1]), acc[i][1], 0, 0, 0);
+                }
+            }
+        });
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1507,6 +1511,8 @@ int dispatch(const sp_conv_params& p, hipStream_t s) {
     if (sizeof(T) == 2 && p.ksize == 3 && p.cin_p == 8 && p.cout % 16 == 0 && p.cout <= 64 && (p.ldy & 7) == 0 && !p.pool2 && !p.in_up2 &&
         p.h % C8_TH == 0 && p.w_ % C8_TW == 0 && sp_tune(SP_TUNE_CONV_CIN8, 1) && sp_tune(SP_TUNE_CONV_TALL, 1) <= 1)   // (forced tall modes: tests)
         return launch_cin8(p, s);
+    if (sizeof(T) == 2 && p.ksize == 1 && p.cin_p > 1024 && ((M + 31) / 32) * ((p.cout + 63) / 64) <= sp_tune(SP_TUNE_CONV1X1_SPLITK, 320))
+        return launch_1x1_splitk(p, s);                 // (small maps only: the wide networks' deepest 1x1 input gradients; larger maps fall through)
     if (sizeof(T) == 2 && p.ksize == 1 && p.cin_p <= 1024) {
         // small maps: K split over the waves of a block, as long as the blocks (32 pixels x 64 channels each, every one
         // streaming its whole 64 x Cin weight tile from L2) stay few: beyond ~320 the LDS-staged tile of the direct kernel wins

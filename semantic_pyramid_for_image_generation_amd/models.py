@@ -601,6 +601,7 @@ class _VGGPyramidFn(torch.autograd.Function):
         import ctypes
         Lb = ops.L
         dev = img.device
+        ops.PROBE_NET[0] = "vgg"          # bench.py's launch probe: everything until the return below belongs to the frozen pyramid
         n_grad = img.shape[0]
         n = n_grad + (img_b.shape[0] if img_b is not None else 0)
         scale = tuple(1.0 / s for s in _IMAGENET_STD)
@@ -660,7 +661,7 @@ class _VGGPyramidFn(torch.autograd.Function):
                 ci += 1
                 if calibrating:                                          # plain bf16 layer this once (the recorded maxima set the scales)
                     y = ops.nhwc_empty(n, v, h, w, dtype, dev)
-                    ops.conv_launch(x, pk["fwd"].data_ptr(), pk["bias"], y, None, None, None, 0.0, n, h, w, x.shape[1], v, v, 3, ACT_RELU, dtype)
+                    ops.conv_launch(x, pk["fwd"].data_ptr(), pk["bias"], y, None, None, None, 0.0, n, h, w, x.shape[1], v, v, 3, ACT_RELU, dtype, k_real=pk["cin"])
                     x8 = None
                     trace.append(("conv", len(acts) - 1, pk))
                 else:
@@ -689,7 +690,7 @@ class _VGGPyramidFn(torch.autograd.Function):
                 if fuse_pool and k + 1 < len(_VGG_CFG) and _VGG_CFG[k + 1] == "M" and ops.conv_pool2_ok(h, w, v, 3):
                     y = ops.nhwc_empty(n, v, h // 2, w // 2, dtype, dev)
                     ops.conv_launch(x, pk["fwd"].data_ptr(), pk["bias"], y, None, None, None, 0.0, n, h, w, x.shape[1], v, v, 3, ACT_RELU,
-                                    dtype, pool2=2)
+                                    dtype, pool2=2, k_real=pk["cin"])
                     skip_pool = True
                 elif (n > n_grad and _FUSE_POOL2 and v <= 128 and k + 1 < len(_VGG_CFG) and _VGG_CFG[k + 1] == "M"
                       and ops.conv_pool2_ok(h, w, v, 3)):
@@ -699,21 +700,21 @@ class _VGGPyramidFn(torch.autograd.Function):
                     # its full-resolution tensor (168 / 84 MB) is neither written nor read back by a pooling pass
                     yf = ops.nhwc_empty(n_grad, v, h, w, dtype, dev)
                     ops.conv_launch(x[:n_grad], pk["fwd"].data_ptr(), pk["bias"], yf, None, None, None, 0.0, n_grad, h, w, x.shape[1], v, v, 3,
-                                    ACT_RELU, dtype)
+                                    ACT_RELU, dtype, k_real=pk["cin"])
                     trace.append(("conv", len(acts) - 1, pk))
                     acts.append(yf)
                     y = ops.nhwc_empty(n, v, h // 2, w // 2, dtype, dev)
                     Lb.call("sp_maxpool2_fwd", ops.ptr(yf), ops.ptr(y), n_grad, h, w, v, 0, ops.sp_dtype(dtype), ops.stream())
                     trace.append(("pool", len(acts) - 1))
                     ops.conv_launch(x[n_grad:], pk["fwd"].data_ptr(), pk["bias"], y[n_grad:], None, None, None, 0.0, n - n_grad, h, w, x.shape[1],
-                                    v, v, 3, ACT_RELU, dtype, pool2=2)
+                                    v, v, 3, ACT_RELU, dtype, pool2=2, k_real=pk["cin"])
                     skip_pool = True
                     x = y
                     acts.append(x)
                     continue
                 else:
                     y = ops.nhwc_empty(n, v, h, w, dtype, dev)
-                    ops.conv_launch(x, pk["fwd"].data_ptr(), pk["bias"], y, None, None, None, 0.0, n, h, w, x.shape[1], v, v, 3, ACT_RELU, dtype)
+                    ops.conv_launch(x, pk["fwd"].data_ptr(), pk["bias"], y, None, None, None, 0.0, n, h, w, x.shape[1], v, v, 3, ACT_RELU, dtype, k_real=pk["cin"])
                 trace.append(("conv", len(acts) - 1, pk))
             x = y
             acts.append(x)
@@ -744,6 +745,7 @@ class _VGGPyramidFn(torch.autograd.Function):
         ctx.save_for_backward(*acts, p7, h1, h2)
         ctx.n_acts = len(acts)
         ctx.n_grad = n_grad
+        ops.PROBE_NET[0] = "sn"
         if img_b is None:
             return tuple(feats)
         second = tuple(f[n_grad:] for f in feats)                # batch-outermost layouts: both halves are dense
@@ -753,6 +755,7 @@ class _VGGPyramidFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *dfeats):
         Lb = ops.L
+        ops.PROBE_NET[0] = "vgg"
         saved = ctx.saved_tensors
         acts = saved[:ctx.n_acts]
         p7, h1, h2 = saved[ctx.n_acts:]
@@ -821,6 +824,7 @@ class _VGGPyramidFn(torch.autograd.Function):
                 ops.conv_launch(g, pk["dgrad"].data_ptr(), None, dx, res1, None, xin if producer_is_conv else None, 0.0, n, h, w,
                                 g.shape[1], pk["cin"], cin_p, 3, ACT_NONE, dtype, family="dgrad")
                 g = dx
+        ops.PROBE_NET[0] = "sn"
         if g is None:
             return None, None, None, None
         shape, src_dtype = ctx.img_meta

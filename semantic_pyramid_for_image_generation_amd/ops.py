@@ -611,15 +611,20 @@ def packed_layer(module, training: bool, dtype, device) -> PackedLayer:
 # bench.py sets this to a list to time the convolution launches with events on the launch stream (eager steps only): entries
 # (start, end, algorithmic flops, family in {"fwd", "dgrad", "wgrad"}, is_dominant_kernel)
 KERNEL_PROBE = None
+# which network the probed launches belong to: "sn" = the spectral-normalised layers of G and D (the north-star's "3x3 spectral-norm
+# conv backward" is a sub-total over these), "vgg" while the frozen pyramid runs (models._VGGPyramidFn sets it)
+PROBE_NET = ["sn"]
 
 
 def _probed(family: str, flops: float, dominant: bool, fn, shape=None) -> None:
+    """flops: EXECUTED multiply-adds x 2 of the launch on the layer's real channel counts (zero-padded channels - RGB 3 -> 8,
+    513 -> 520 - are not work)."""
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     fn()
     e1.record()
     route = L.lib().sp_last_route().decode()          # the kernel the entry point chose (include/sempyr.h: sp_last_route)
-    KERNEL_PROBE.append((e0, e1, flops, family, dominant, route, shape))
+    KERNEL_PROBE.append((e0, e1, flops, family, dominant, route, shape, PROBE_NET[0]))
 
 
 def _is_halo128(n, h, w, cout, ksize) -> bool:
@@ -648,9 +653,11 @@ def set_tuning(key: int, value: int) -> None:
 
 
 def conv_launch(x, w_ptr: int, bias, y, res1, res2, mask_src, slope: float, n, h, w, cin_p, cout, ldy, ksize, act,
-                dtype, pool2: bool = False, in_up2: bool = False, family: str = "fwd", img_scale: int = 0, img_split: int = 0) -> None:
+                dtype, pool2: bool = False, in_up2: bool = False, family: str = "fwd", img_scale: int = 0, img_split: int = 0,
+                k_real: Optional[int] = None) -> None:
+    """k_real: the layer's real reduction channels where cin_p counts zero padding (bench.py's FLOP bookkeeping only)."""
     if KERNEL_PROBE is not None:
-        _probed(family, 2.0 * n * h * w * cin_p * cout * ksize * ksize, _is_halo128(n, h, w, cout, ksize),
+        _probed(family, 2.0 * n * h * w * (k_real if k_real is not None else cin_p) * cout * ksize * ksize, _is_halo128(n, h, w, cout, ksize),
                 lambda: _conv_launch(x, w_ptr, bias, y, res1, res2, mask_src, slope, n, h, w, cin_p, cout, ldy, ksize, act, dtype, pool2, in_up2,
                                      img_scale, img_split),
                 (ksize, cin_p, cout, h, w, n))
@@ -794,7 +801,7 @@ class _ConvFn(torch.autograd.Function):
         # pool2: y (and res1 / res2) live at the pooled resolution - avgpool2(conv) + bias + residuals, one launch
         y = nhwc_empty(n, cout, h // 2, w // 2, x.dtype, x.device) if pool2 else nhwc_empty(n, cout, h, w, x.dtype, x.device)
         conv_launch(x, pl.fwd, bias, y, res1, res2, None, 0.0, n, h, w, cin_p, cout, cout, ksize, act, x.dtype, pool2,
-                    img_scale=img_scale, img_split=img_split)
+                    img_scale=img_scale, img_split=img_split, k_real=pl.cin)
         ctx.pl, ctx.ksize, ctx.act, ctx.cout = pl, ksize, act, cout
         ctx.has_res = (res1 is not None, res2 is not None)
         ctx.save_for_backward(x, y if act != ACT_NONE else None)
@@ -836,7 +843,7 @@ class _ConvFn(torch.autograd.Function):
             pair = ctx.pair
             conv_launch(dz, pl.dgrad, None, dx, None, None, x if ctx.mask_input else None, 0.2, n, h, w, pl.cout_p, pl.cin, cin_p,
                         ksize, ACT_NONE, dt, in_up2=up2, family="dgrad", img_scale=pair.scale_ptr(pl.slot) if pair is not None else 0,
-                        img_split=pair.split if pair is not None else 0)
+                        img_split=pair.split if pair is not None else 0, k_real=cout)
         dhb = None
         if need[1] and ctx.pair is not None:
             # two-group batch: one weight-gradient launch per group (contiguous image ranges of x and dz), each into the arena of
@@ -858,7 +865,7 @@ class _ConvFn(torch.autograd.Function):
                 L.call("sp_conv2d_wgrad_accum_pair", ptr(x), ptr(dz), ptr(dwa), ptr(dba), ptr(dwb), ptr(dbb), ptr(ws), wsg, n, pair.split, h, w,
                        cin_p, cout, cout_p, ksize, 1 if up2 else 0, sp_dtype(dt), stream())
             if KERNEL_PROBE is not None:
-                _probed("wgrad", 2.0 * n * h * w * cin_p * cout * ksize * ksize, False, launch_wgrad, (ksize, cin_p, cout, h, w, n))
+                _probed("wgrad", 2.0 * n * h * w * pl.cin * cout * ksize * ksize, False, launch_wgrad, (ksize, cin_p, cout, h, w, n))
             elif _wgrad_aside(h, w):
                 _on_wgrad_stream(launch_wgrad, [x, dz, ws])
             else:
@@ -876,7 +883,7 @@ class _ConvFn(torch.autograd.Function):
                 L.call("sp_conv2d_wgrad_accum_pooled" if up2 else "sp_conv2d_wgrad_accum", ptr(x), ptr(dz), ptr(dwsn), ptr(db), ptr(ws),
                        ws_floats, n, h, w, cin_p, cout, cout_p, ksize, sp_dtype(dt), stream())
             if KERNEL_PROBE is not None:
-                _probed("wgrad", 2.0 * n * h * w * cin_p * cout * ksize * ksize, False, launch_wgrad, (ksize, cin_p, cout, h, w, n))
+                _probed("wgrad", 2.0 * n * h * w * pl.cin * cout * ksize * ksize, False, launch_wgrad, (ksize, cin_p, cout, h, w, n))
             elif _wgrad_aside(h, w) and pl.call.bank.direct_grads:
                 _on_wgrad_stream(launch_wgrad, [x, dz, ws])
             else:
@@ -945,7 +952,7 @@ def sn_conv2d_tail(x, m3, act3: int, m1, act1: int) -> torch.Tensor:
     def launch():
         L.call("sp_conv2d_igemm", ctypes.byref(p), stream())
     if KERNEL_PROBE is not None:
-        _probed("fwd", 2.0 * n * h * w * 64 * (9 * cin_p + cout1), False, launch, (3, cin_p, 64, h, w, n))
+        _probed("fwd", 2.0 * n * h * w * 64 * (9 * pl3.cin + cout1), False, launch, (3, cin_p, 64, h, w, n))
     else:
         launch()
     return y
@@ -997,7 +1004,7 @@ class _ReusedLayerFn(torch.autograd.Function):
                 L.call("sp_conv2d_wgrad_accum", ptr(x), ptr(dy), ptr(dwsn), ptr(db), ptr(ws), ws_floats, n, h, w, cin_p, cout, cout_p, ksize,
                        sp_dtype(dt), stream())
             if KERNEL_PROBE is not None:
-                _probed("wgrad", 2.0 * n * h * w * cin_p * cout * ksize * ksize, False, launch, (ksize, cin_p, cout, h, w, n))
+                _probed("wgrad", 2.0 * n * h * w * pl.cin * cout * ksize * ksize, False, launch, (ksize, cin_p, cout, h, w, n))
             else:
                 launch()
         else:

@@ -245,3 +245,34 @@ def test_ranks_agree_on_the_outcome_of_a_graph_capture():
         assert len(results) == world
         for r in range(world):
             assert results[r] == (False, True), (r, results[r])
+
+
+def _oracle_side_worker(rank, world, port, results):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(3)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import _two_rank_step as T
+        G, D, red_g, red_d, losses = T.oracle_run(rank, world)
+        from oracle import sempyr_oracle as O
+        results[rank] = (T.digest(O.trainable(G) + O.trainable(D)), T.digest([g for step in red_d + red_g for g in step]),
+                         float(red_d[0][0].abs().sum()), losses)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_expectation_of_the_two_rank_gpu_job():
+    """The oracle side of tests/test_gpu_two_ranks.py (which needs a GPU for its other half): two gloo ranks, each on its own
+    shard, with optimizers that average the gradients before Adam - both ranks end with bit-identical parameters and reduced
+    gradients although their losses (their shards) differ."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    world = 2
+    port = _free_port()
+    with mp.Manager() as mgr:
+        results = mgr.dict()
+        mp.spawn(_oracle_side_worker, args=(world, port, results), nprocs=world, join=True)
+        assert len(results) == world
+        (p0, g0, s0, l0), (p1, g1, s1, l1) = results[0], results[1]
+        assert p0 == p1 and g0 == g1 and s0 == s1 and s0 > 0
+        assert l0 != l1

@@ -295,7 +295,10 @@ def test_wgrad_row_walker_narrow_maps_bf16(case):
 
 
 SPLITK_1X1_CASES = [(768, 512, 1, 20, 2, 2), (512, 512, 1, 20, 4, 4), (256, 256, 1, 20, 8, 8), (520, 136, 1, 1, 5, 7), (256, 30, 1, 1, 6, 6),
-                    (128, 64, 1, 3, 3, 3), (512, 768, 1, 2, 2, 2)]
+                    (128, 64, 1, 3, 3, 3), (512, 768, 1, 2, 2, 2),
+                    # channel_factor 0.5: Cin / Cout beyond 1024 (the K-steps of a wave in two or more chunks; 1040: a ragged last chunk) -
+                    # forward on 1536 / 1040 input channels, and the 1024 -> 1536 layer's input gradient (K = 1536) through dgrad
+                    (1536, 1024, 1, 40, 2, 2), (1024, 1536, 1, 40, 2, 2), (1040, 72, 1, 3, 3, 5)]
 
 
 @pytest.mark.parametrize("case", [(64, 64, 3, 2, 32, 32), (128, 96, 3, 2, 16, 16), (256, 64, 1, 2, 16, 16), (32, 48, 3, 3, 32, 32)])
