@@ -151,6 +151,13 @@ typedef struct sp_conv_params {
     const float* tail_bias;
     void* tail_y;
     int32_t tail_cout, tail_act, tail_ld, reserved2_;
+    /* pool2 == 2 only (conv -> ReLU -> MaxPool2d(2), the VGG-16 stages of /root/reference/models.py:183-216 in the pass WITH gradient):
+     * where to leave the window position of every pooled element, so that the unpooled tensor never reaches HBM and the pooling's
+     * backward (sp_maxpool2_bwd_idx) needs neither it nor a recomputation.  One uint32 per (pooled pixel, group of 16 channels),
+     * [n * (h/2) * (w/2)][cout / 16]: bits 2c .. 2c+1 = 2 * row + column of the FIRST maximum (scan order, as torch's max_pool2d
+     * routes its gradient) of channel 16 g + c, taken over the values as the storage type holds them - exactly the element
+     * sp_maxpool2_bwd would pick from the stored unpooled tensor.  NULL: not recorded. */
+    uint32_t* pool_idx;
 } sp_conv_params;
 int sp_conv2d_igemm(const sp_conv_params* p, sp_stream_t stream);
 /* Bytes of fp32 scratch sp_conv2d_igemm wants in sp_conv_params.workspace to split the K loop of this shape over several
@@ -353,6 +360,11 @@ int sp_maxpool2_fwd(const void* x, void* y, int32_t n, int32_t h, int32_t w_, in
                     sp_stream_t stream);
 int sp_maxpool2_bwd(const void* dy, const void* x, void* dx, int32_t n, int32_t h, int32_t w_, int32_t c,
                     int32_t relu, int32_t dtype, sp_stream_t stream);
+/* Backward of conv -> ReLU -> MaxPool2d(2) from what the fused epilogue left behind (sp_conv_params.pool_idx): dx [n][h][w][c] gets
+ * dy [n][h/2][w/2][c] at the recorded window position where the pooled value y is positive, zero elsewhere - bit for bit what
+ * sp_maxpool2_bwd(relu = 1) computes from the unpooled tensor.  c % 16 == 0. */
+int sp_maxpool2_bwd_idx(const void* dy, const void* y, const uint32_t* idx, void* dx, int32_t n, int32_t h, int32_t w_, int32_t c,
+                        int32_t dtype, sp_stream_t stream);
 int sp_adaptive_avgpool_fwd(const void* x, void* y, int32_t n, int32_t h, int32_t w_, int32_t c, int32_t oh,
                             int32_t ow, int32_t act_in, int32_t dtype, sp_stream_t stream);
 int sp_adaptive_avgpool_bwd(const void* dy, const void* x, void* dx, int32_t n, int32_t h, int32_t w_, int32_t c,

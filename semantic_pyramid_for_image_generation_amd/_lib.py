@@ -41,7 +41,8 @@ class SpConvParams(ctypes.Structure):
                 ("img_scale", ctypes.c_void_p), ("img_split", ctypes.c_int32), ("reserved_", ctypes.c_int32),
                 ("split_pix_", ctypes.c_int64),
                 ("tail_w", ctypes.c_void_p), ("tail_bias", ctypes.c_void_p), ("tail_y", ctypes.c_void_p),
-                ("tail_cout", ctypes.c_int32), ("tail_act", ctypes.c_int32), ("tail_ld", ctypes.c_int32), ("reserved2_", ctypes.c_int32)]
+                ("tail_cout", ctypes.c_int32), ("tail_act", ctypes.c_int32), ("tail_ld", ctypes.c_int32), ("reserved2_", ctypes.c_int32),
+                ("pool_idx", ctypes.c_void_p)]
 
 
 class SpSnLayer(ctypes.Structure):

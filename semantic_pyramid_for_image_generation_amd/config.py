@@ -21,6 +21,7 @@ results beyond floating-point summation order.  The kernel library itself reads 
     wgrad_side_stream     SP_WGRAD_SIDE_STREAM   0        weight-gradient launches on a side stream (a parallel graph branch): 1 = all layers, N = maps of <= N pixels - experiment
     reuse_feature_maps    SP_REUSE_FEATURE_MAPS  1        the generator's masked-feature mappings of the G step derived from the D step's forward (same inputs, same weights, other sigma)
     vgg_pair              SP_VGG_PAIR            1        the VGG-16 pyramid of the NEXT batch's real images rides in the generator step's pass over the fake images (one pass over 2B images; ModelWrapper.train_step(next_images_real=...))
+    vgg_pool_idx          SP_VGG_POOL_IDX        1        VGG-16 pass WITH gradient: a stage's last convolution stores the pooled output + 2-bit window positions instead of the unpooled tensor (sp_conv_params.pool_idx)
     f16_loss_scale        SP_F16_LOSS_SCALE      65536    static loss scale of the fp16 storage mode (ops.set_compute_dtype(torch.float16))
     vgg_fp8               SP_VGG_FP8             0        BASELINE.json config 5's fp8 slice: VGG-16's wide 3x3 layers on the fp8 MFMA in the no-gradient pass (ops.set_vgg_fp8)
     lib_path              SEMPYR_LIB             (in-tree libsempyr.so)
@@ -54,6 +55,7 @@ class Config:
     wgrad_side_stream: int = 0
     reuse_feature_maps: bool = True
     vgg_pair: bool = True
+    vgg_pool_idx: bool = True
 
     @classmethod
     def from_env(cls) -> "Config":
@@ -64,7 +66,8 @@ class Config:
                    d_pair=_flag("SP_D_PAIR", True), f16_loss_scale=float(os.environ.get("SP_F16_LOSS_SCALE", "65536")),
                    side_features=_flag("SP_SIDE_FEATURES", False),
                    fuse_upsample_bn=_flag("SP_FUSE_UPSAMPLE_BN", True), fuse_tail=_flag("SP_FUSE_TAIL", True),
-                   wgrad_side_stream=int(os.environ.get("SP_WGRAD_SIDE_STREAM", "0")), reuse_feature_maps=_flag("SP_REUSE_FEATURE_MAPS", True), vgg_pair=_flag("SP_VGG_PAIR", True))
+                   wgrad_side_stream=int(os.environ.get("SP_WGRAD_SIDE_STREAM", "0")), reuse_feature_maps=_flag("SP_REUSE_FEATURE_MAPS", True), vgg_pair=_flag("SP_VGG_PAIR", True),
+                   vgg_pool_idx=_flag("SP_VGG_POOL_IDX", True))
 
 
 CFG = Config.from_env()

@@ -181,6 +181,52 @@ __device__ __forceinline__ void conv_epilogue_pool2(const sp_conv_params& p, con
     conv_epilogue16<T>(p, v, ppix_row + pcol0 + (odd ? 8 : 0) + ((lane & 15) >> 1), co, add_bias);
 }
 
+// pool2 == 2 with sp_conv_params.pool_idx: the maximum AND its window position.  a0 / a1: the lane's column of half a in the upper /
+// lower row of the pair, b0 / b1 likewise for half b (raw accumulators).  The position is the FIRST maximum in scan order
+// (row 0: columns 0, 1; row 1: columns 0, 1 - a later element wins only if strictly greater, as in sp_maxpool2_bwd and torch) over
+// the values the separate path would have stored and compared: accumulator (+ bias) rounded to the storage type (ReLU is monotonic
+// and decides nothing where the maximum is positive; where it is not, the gradient is zero whatever the position).
+template <typename T> __device__ __forceinline__ float round_to_storage(float v);
+template <> __device__ __forceinline__ float round_to_storage<float>(float v) { return v; }
+template <> __device__ __forceinline__ float round_to_storage<bf16>(float v) { return bf16_bits_to_f32(f32_to_bf16_bits(v)); }
+template <typename T>
+__device__ __forceinline__ void conv_epilogue_pool2_idx(const sp_conv_params& p, const float (&a0)[16], const float (&a1)[16],
+                                                        const float (&b0)[16], const float (&b1)[16], int lane, long ppix_row, int pcol0,
+                                                        int co, bool add_bias = true) {
+    if (co + 16 > p.cout) return;
+    const bool odd = lane & 1;
+    float bias[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) bias[c] = 0.f;
+    if (p.bias && add_bias) Wide16<float>::ld(p.bias + co, bias);
+    // even lanes finish the pooled pixel of half a (they hold its even column, lane ^ 1 the odd one), odd lanes the one of half b.
+    // Channel by channel (value and row flag travel through one DPP move each): nothing but v[] and idx lives across the loop -
+    // these kernels have no register to spare beside their accumulators, and a spill would put scratch traffic on the counted
+    // vmcnt waits of their LDS-DMA pipelines
+    float v[16];
+    unsigned idx = 0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const float ra0 = round_to_storage<T>(a0[c] + bias[c]), ra1 = round_to_storage<T>(a1[c] + bias[c]);
+        const float rb0 = round_to_storage<T>(b0[c] + bias[c]), rb1 = round_to_storage<T>(b1[c] + bias[c]);
+        const bool fa = ra1 > ra0, fb = rb1 > rb0;                            // the vertical maximum sits in row 1 (only if strictly greater)
+        const float ma = fa ? ra1 : ra0, mb = fb ? rb1 : rb0;
+        const float mine = odd ? mb : ma;
+        const int mine_row = (odd ? fb : fa) ? 1 : 0;
+        const float recv = dpp_xor1(odd ? ma : mb);
+        const int recv_row = __builtin_amdgcn_update_dpp(0, (odd ? fa : fb) ? 1 : 0, 0xB1, 0xF, 0xF, true);
+        // column 0 of the window is the even lane's, column 1 the odd lane's
+        const float m0 = odd ? recv : mine, m1 = odd ? mine : recv;
+        const int r0 = odd ? recv_row : mine_row, r1 = odd ? mine_row : recv_row;
+        const bool col1 = m1 > m0 || (m1 == m0 && r1 < r0);
+        v[c] = col1 ? m1 : m0;
+        idx |= (unsigned)(col1 ? (2 * r1 + 1) : (2 * r0)) << (2 * c);
+    }
+    const long ppix = ppix_row + pcol0 + (odd ? 8 : 0) + ((lane & 15) >> 1);
+    p.pool_idx[ppix * (p.cout >> 4) + (co >> 4)] = idx;
+    conv_epilogue16<T>(p, v, ppix, co, false);                            // (bias already added; no scale, mask or residuals with pool2 == 2)
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 template <int OFF> __device__ __forceinline__ void lds_rd128(uint4& d, unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "i"(OFF));

@@ -220,7 +220,7 @@ constexpr int HALO_W = 40;                       // LDS row pitch in pixels: a m
                                                  // down (tap row) leaves the swizzle key (pixel & 7) unchanged
 constexpr int HALO_PIX = (HALO_TH + 2) * HALO_W;
 
-template <typename T, int CO_T, int TPS>
+template <typename T, int CO_T, int TPS, bool IDX = false>           // IDX: pool2 == 2 with sp_conv_params.pool_idx (its own instantiation)
 __global__ __launch_bounds__(CO_T * 4) void conv3x3_halo_kernel(sp_conv_params p) {
     constexpr int NT = CO_T * 4;                 // 8 waves for 128 output channels, 4 waves for 64
     constexpr int E = 16 / (int)sizeof(T);
@@ -391,6 +391,19 @@ __global__ __launch_bounds__(CO_T * 4) void conv3x3_halo_kernel(sp_conv_params p
             for (int j = 0; j < FPX; ++j) acc[i][j] *= 0.25f;
     }
     if (p.pool2) {                                                  // launcher guarantees `wide` for every lane
+        const long prow = ((long)n * (H >> 1) + ((ty0 >> 1) + wpx)) * (W >> 1);
+        if constexpr (IDX) {                                         // maximum + its window position (the VGG pass with gradient)
+            float a0[16], a1[16], b0[16], b1[16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    a0[i * 4 + r] = acc[i][0][r]; a1[i * 4 + r] = acc[i][2][r];
+                    b0[i * 4 + r] = acc[i][1][r]; b1[i * 4 + r] = acc[i][3][r];
+                }
+            conv_epilogue_pool2_idx<T>(p, a0, a1, b0, b1, lane, prow, tx0 >> 1, co_b);
+            return;
+        }
         float a[16], b[16];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -399,7 +412,6 @@ __global__ __launch_bounds__(CO_T * 4) void conv3x3_halo_kernel(sp_conv_params p
                 a[i * 4 + r] = pool2_combine(acc[i][0][r], acc[i][2][r], p.pool2 == 2);
                 b[i * 4 + r] = pool2_combine(acc[i][1][r], acc[i][3][r], p.pool2 == 2);
             }
-        const long prow = ((long)n * (H >> 1) + ((ty0 >> 1) + wpx)) * (W >> 1);
         conv_epilogue_pool2<T>(p, a, b, lane, prow, tx0 >> 1, co_b);
         return;
     }
@@ -427,11 +439,11 @@ __global__ __launch_bounds__(CO_T * 4) void conv3x3_halo_kernel(sp_conv_params p
     });
 }
 
-template <typename T, int CO_T, int TPS>
+template <typename T, int CO_T, int TPS, bool IDX = false>
 int launch_halo(const sp_conv_params& p, hipStream_t s) {
     constexpr int LDS = HALO_PIX * 128 + 2 * TPS * CO_T * 128;
     static bool attr_set = false;
-    auto kern = conv3x3_halo_kernel<T, CO_T, TPS>;
+    auto kern = conv3x3_halo_kernel<T, CO_T, TPS, IDX>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) { sp_set_error("hipFuncSetAttribute(LDS=%d) failed: %s", LDS, hipGetErrorString(e)); return SP_ERR_LAUNCH; }
@@ -694,7 +706,7 @@ constexpr int g_num_cu = 256;                          // MI355X
 // exposed prologue per tile.
 // TH = patch height: 16 (the tall tile) or 8 (WCO = 2 only: the halo kernel's 128 co x 8x32 tile on this kernel's LDS-DMA
 // pipeline; a wave then owns 2 rows, 64 accumulator registers, and keeps all 12 A fragments of a stage live: IH = 1).
-template <typename T, int WCO, int TH = 16>
+template <typename T, int WCO, int TH = 16, bool IDX = false>          // IDX: pool2 == 2 with sp_conv_params.pool_idx (its own instantiation)
 __global__ __launch_bounds__(512) void conv3x3_tall_kernel(sp_conv_params p, int cotiles, int total, int stagger) {
     constexpr int TL_TH = TH, TL_HR = TH + 2;          // shadow the file-scope constants
     constexpr int E = 16 / (int)sizeof(T);
@@ -968,16 +980,28 @@ __global__ __launch_bounds__(512) void conv3x3_tall_kernel(sp_conv_params p, int
                 const long pix = pix0 + (long)(j >> 1) * W + (j & 1) * 16;
                 if (p.pool2) {                                           // launcher guarantees `wide`
                     if constexpr ((j & 3) == 0) {                        // fragments j..j+3 = rows (j>>1, j>>1 + 1) x column halves
-                        float a[16], b[16];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                a[i * 4 + r] = pool2_combine(acc[i][j][r], acc[i][j + 2][r], p.pool2 == 2);
-                                b[i * 4 + r] = pool2_combine(acc[i][j + 1][r], acc[i][j + 3][r], p.pool2 == 2);
-                            }
                         const long prow = ((long)n * (H >> 1) + ((ty0 + RW * wpx + (j >> 1)) >> 1)) * (W >> 1);
-                        conv_epilogue_pool2<T>(p, a, b, lane, prow, tx0 >> 1, co_b, !bias_in_acc);
+                        if constexpr (IDX) {                             // maximum + its window position (the VGG pass with gradient)
+                            float a0[16], a1[16], b0[16], b1[16];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    a0[i * 4 + r] = acc[i][j][r]; a1[i * 4 + r] = acc[i][j + 2][r];
+                                    b0[i * 4 + r] = acc[i][j + 1][r]; b1[i * 4 + r] = acc[i][j + 3][r];
+                                }
+                            conv_epilogue_pool2_idx<T>(p, a0, a1, b0, b1, lane, prow, tx0 >> 1, co_b, !bias_in_acc);
+                        } else {
+                            float a[16], b[16];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    a[i * 4 + r] = pool2_combine(acc[i][j][r], acc[i][j + 2][r], p.pool2 == 2);
+                                    b[i * 4 + r] = pool2_combine(acc[i][j + 1][r], acc[i][j + 3][r], p.pool2 == 2);
+                                }
+                            conv_epilogue_pool2<T>(p, a, b, lane, prow, tx0 >> 1, co_b, !bias_in_acc);
+                        }
                     }
                 } else if (wide) {
                     float v[16];
@@ -1006,12 +1030,12 @@ __global__ __launch_bounds__(512) void conv3x3_tall_kernel(sp_conv_params p, int
     }
 }
 
-template <typename T, int WCO, int TH = 16>
+template <typename T, int WCO, int TH = 16, bool IDX = false>
 int launch_tall(const sp_conv_params& p, hipStream_t s) {
     constexpr int HP = WCO == 1 ? 36 : 40;
     constexpr int LDS = 2 * ((((TH + 2) * HP * 64 + 1023) / 1024) * 1024) + 2 * (WCO == 1 ? 9 : 3) * 64 * WCO * 64;
     static bool attr_set = false;
-    auto kern = conv3x3_tall_kernel<T, WCO, TH>;
+    auto kern = conv3x3_tall_kernel<T, WCO, TH, IDX>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) { sp_set_error("hipFuncSetAttribute(LDS=%d) failed: %s", LDS, hipGetErrorString(e)); return SP_ERR_LAUNCH; }
@@ -1523,6 +1547,21 @@ int dispatch(const sp_conv_params& p, hipStream_t s) {
     }
     // cout <= 16 on a big feature map (the generator's RGB head, 64 -> 3 @256^2): memory-bound; the halo-reuse kernels read
     // the input once instead of once per tap, which outweighs the idle MFMA rows (158 -> ~85 us)
+    if (p.pool_idx != nullptr) {
+        // ReLU + MaxPool with recorded window positions (pool2 == 2, the API checked h % 8 == 0, w % 32 == 0, cout > 32, cout % 16 == 0):
+        // its own instantiations of a fixed set of kernels, so that the hot ones keep their register allocation - 16-bit: the
+        // ping-pong kernel's general epilogue (64 co x 16x32 / 128 co x 8x32 tiles); fp32, and what the ping-pong launcher declines:
+        // the LDS-DMA tall kernel on the same tiles; Cout <= 64 with h % 16 != 0: the register-staged halo kernel
+        const long esz = p.dtype == SP_F32 ? 4 : 2;
+        const bool fits30 = (long)p.n * p.h * p.w_ * p.cin_p * esz < (1L << 30) && (long)p.cout * 9 * p.cin_p * esz < (1L << 30);
+        if (p.cout <= 64 && p.h % TL_TH != 0) return launch_halo<T, 64, 1, true>(p, s);
+        if (!fits30) { sp_set_error("sp_conv2d_igemm: pool_idx needs operands below 1 GiB (n*h*w*cin_p, cout*9*cin_p)"); return SP_ERR_UNSUPPORTED; }
+        if (sizeof(T) == 2 && sp_tune(SP_TUNE_CONV_PP, 1)) {
+            const int rc = sp_conv_pp_launch(p, p.cout <= 64 ? 16 : 8, s);
+            if (rc != 1) return rc;
+        }
+        return p.cout <= 64 ? launch_tall<T, 1, 16, true>(p, s) : launch_tall<T, 2, 8, true>(p, s);
+    }
     const bool thin_big = p.cout <= 16 && p.cin_p >= 32 && M >= (1L << 18);
     if (p.ksize == 3 && (p.cout > 32 || thin_big) && p.h % HALO_TH == 0 && p.w_ % HALO_TW == 0) {
         // persistent tall kernel (half the LDS reads per MFMA, LDS-DMA pipeline across tiles); SP_CONV_TALL=0 disables, 2 forces
@@ -1637,6 +1676,8 @@ extern "C" int sp_conv2d_igemm(const sp_conv_params* pp, sp_stream_t stream) {
         SP_CHECK_ARG(p.ksize == 3 && p.cout > 32 && p.h % HALO_TH == 0 && p.w_ % HALO_TW == 0,
                      "sp_conv2d_igemm: in_up2 needs a 3x3 layer with cout > 32, h %% 8 == 0, w %% 32 == 0");
     SP_CHECK_ARG(p.pool2 >= 0 && p.pool2 <= 2, "sp_conv2d_igemm: pool2 must be 0, 1 (average) or 2 (maximum)");
+    SP_CHECK_ARG(p.pool_idx == nullptr || (p.pool2 == 2 && p.img_scale == nullptr && p.dtype != SP_F8),
+                 "sp_conv2d_igemm: pool_idx goes with pool2 == 2 (maximum), without img_scale");
     if (p.pool2 == 2)
         SP_CHECK_ARG(p.res1 == nullptr && p.res2 == nullptr && (p.act == SP_ACT_NONE || p.act == SP_ACT_RELU || p.act == SP_ACT_LRELU),
                      "sp_conv2d_igemm: max pooling in the epilogue needs a monotonic activation and no residuals");

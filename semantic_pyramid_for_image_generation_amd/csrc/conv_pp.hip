@@ -79,8 +79,9 @@ constexpr int pp_group_index(int h, int dr, int rw) {
 // tanh.  The general epilogue (per-lane `wide` test, 4-channel and scalar tails, pooling, an inlined tanh per value and call site) is
 // 18 K instructions in ~1 100 basic blocks around a 1.7 K-instruction loop; measured with compile-time assumptions in its place
 // (scratch: -DPP_ASSUME_SIMPLE), a launch of 128->128 @128^2 drops from 170 K to 148 K cycles per block, 64->128 from 111 K to 92 K.
-template <typename T, int WCO, int PRIO, bool TIMING = false, bool DMA_IN_L = true, bool FAST = false, int FW = 2, bool TAIL = false>
+template <typename T, int WCO, int PRIO, bool TIMING = false, bool DMA_IN_L = true, bool FAST = false, int FW = 2, bool TAIL = false, bool IDX = false>
 __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int cotiles, int total, int prio) {
+    static_assert(!IDX || (!FAST && sizeof(T) == 2), "pool_idx: the general 16-bit epilogue");
     static_assert(!TAIL || (FAST && WCO == 1 && FW == 2), "the fused 1x1 tail lives in the 64-channel FAST form");
     using G = PPGeom<T, WCO, FW>;
     static_assert(FW == 2 || (sizeof(T) == 2 && FAST), "16-wide tiles: bf16, FAST epilogue (no pooling)");
@@ -584,16 +585,28 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
                 const long pix = pix0 + (long)(j >> 1) * W + (j & 1) * 16;
                 if (p.pool2) {                                           // launcher guarantees `wide`
                     if constexpr ((j & 3) == 0) {                        // fragments j..j+3 = rows (j>>1, j>>1 + 1) x column halves
-                        float av[16], bv[16];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                av[i * 4 + r] = pool2_combine(acc[i][j][r], acc[i][j + 2][r], p.pool2 == 2);
-                                bv[i * 4 + r] = pool2_combine(acc[i][j + 1][r], acc[i][j + 3][r], p.pool2 == 2);
-                            }
                         const long prow = ((long)n * (H >> 1) + ((ty0 + RW * wpx + (j >> 1)) >> 1)) * (W >> 1);
-                        conv_epilogue_pool2<T>(p, av, bv, lane, prow, tx0 >> 1, co_b, !bias_in_acc);
+                        if constexpr (IDX) {                             // maximum + its window position (the VGG pass with gradient)
+                            float a0[16], a1[16], b0[16], b1[16];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    a0[i * 4 + r] = acc[i][j][r]; a1[i * 4 + r] = acc[i][j + 2][r];
+                                    b0[i * 4 + r] = acc[i][j + 1][r]; b1[i * 4 + r] = acc[i][j + 3][r];
+                                }
+                            conv_epilogue_pool2_idx<T>(p, a0, a1, b0, b1, lane, prow, tx0 >> 1, co_b, !bias_in_acc);
+                        } else {
+                            float av[16], bv[16];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    av[i * 4 + r] = pool2_combine(acc[i][j][r], acc[i][j + 2][r], p.pool2 == 2);
+                                    bv[i * 4 + r] = pool2_combine(acc[i][j + 1][r], acc[i][j + 3][r], p.pool2 == 2);
+                                }
+                            conv_epilogue_pool2<T>(p, av, bv, lane, prow, tx0 >> 1, co_b, !bias_in_acc);
+                        }
                     }
                 } else if (wide) {
                     float v[16];
@@ -655,14 +668,14 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
     }
 }
 
-template <typename T, int WCO, int PRIO, bool TIMING = false, bool DMA_IN_L = true, bool FAST = false, int FW = 2, bool TAIL = false>
+template <typename T, int WCO, int PRIO, bool TIMING = false, bool DMA_IN_L = true, bool FAST = false, int FW = 2, bool TAIL = false, bool IDX = false>
 int launch_pp(const sp_conv_params& p, int prio, hipStream_t s) {
     using G = PPGeom<T, WCO, FW>;
     constexpr int TH = G::TH;
     constexpr int LDS_BYTES = TAIL ? G::LDS_TAIL : G::LDS;
     static_assert(LDS_BYTES <= 163840, "LDS budget");
     static bool attr_set = false;
-    auto kern = conv3x3_pp_kernel<T, WCO, PRIO, TIMING, DMA_IN_L, FAST, FW, TAIL>;
+    auto kern = conv3x3_pp_kernel<T, WCO, PRIO, TIMING, DMA_IN_L, FAST, FW, TAIL, IDX>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) { sp_set_error("hipFuncSetAttribute(LDS=%d) failed: %s", LDS_BYTES, hipGetErrorString(e)); return SP_ERR_LAUNCH; }
@@ -711,6 +724,12 @@ int sp_conv_pp_launch(const sp_conv_params& p, int th, hipStream_t s) {
     if (p.tail_w != nullptr) {                             // the fused 1x1 tail: its own instantiation of the 64-channel FAST form
         if (!(th == 16 && p.cout == 64 && fast)) return 1;
         return launch_pp<bf16, 1, 1, false, true, true, 2, true>(p, prio, s);
+    }
+    if (p.pool_idx != nullptr) {                           // ReLU + MaxPool with recorded window positions: own instantiations (general epilogue)
+        if (p.pool2 != 2) return 1;
+        if (th == 16 && p.cout <= 64) return launch_pp<bf16, 1, 1, false, true, false, 2, false, true>(p, prio, s);
+        if (th == 8 && p.cout > 64) return launch_pp<bf16, 2, 1, false, true, false, 2, false, true>(p, prio, s);
+        return 1;
     }
     if (th == 16 && p.cout <= 64)                          // 64 co x 16x32 px
         return fast ? launch_pp<bf16, 1, 1, false, true, true>(p, prio, s) : launch_pp<bf16, 1, 1>(p, prio, s);

@@ -162,6 +162,32 @@ __global__ void maxpool2_bwd_kernel(const T* __restrict__ dy, const T* __restric
     }
 }
 
+// The same gradient routing from what the convolution's fused ReLU + MaxPool epilogue recorded (sp_conv_params.pool_idx: 2 bits per
+// pooled element = 2 * row + column of the first maximum): the unpooled tensor is not read - it was never written.
+template <typename T, int V>
+__global__ void maxpool2_bwd_idx_kernel(const T* __restrict__ dy, const T* __restrict__ y, const uint32_t* __restrict__ idx,
+                                        T* __restrict__ dx, int N, int H, int W, int C) {
+    const int OH = H / 2, OW = W / 2;
+    const long total = (long)N * OH * OW * (C / V);
+    SP_FOR_VEC(total) {
+        SP_DECODE(i, OH, OW, C)
+        const long ppix = ((long)n * OH + oh) * OW + ow;
+        const long base = (((long)n * H + oh * 2) * W + ow * 2) * C + c;
+        const long offs[4] = {0, C, (long)W * C, (long)W * C + C};
+        float g[V], m[V];
+        VecIO<T, V>::ld(dy + ppix * C + c, g);
+        VecIO<T, V>::ld(y + ppix * C + c, m);
+        const uint32_t word = idx[ppix * (C >> 4) + (c >> 4)] >> (2 * (c & 15));
+        float o[4][V];
+        for (int r = 0; r < V; ++r) {
+            const int best = (int)((word >> (2 * r)) & 3u);
+            const float gv = m[r] > 0.f ? g[r] : 0.f;
+            for (int k = 0; k < 4; ++k) o[k][r] = (k == best) ? gv : 0.f;
+        }
+        for (int k = 0; k < 4; ++k) VecIO<T, V>::st(dx + base + offs[k], o[k]);
+    }
+}
+
 __device__ __forceinline__ int ad_start(int o, int in, int out) { return (int)(((long)o * in) / out); }
 __device__ __forceinline__ int ad_end(int o, int in, int out) { return (int)((((long)o + 1) * in + out - 1) / out); }
 
@@ -440,6 +466,19 @@ extern "C" int sp_maxpool2_bwd(const void* dy, const void* x, void* dx, int32_t 
     if (dtype == SP_F32) hipLaunchKernelGGL((maxpool2_bwd_kernel<float, 4>), dim3(g), dim3(256), 0, s, (const float*)dy, (const float*)x, (float*)dx, n, h, w_, c, relu);
     else if (v == 8) hipLaunchKernelGGL((maxpool2_bwd_kernel<bf16, 8>), dim3(g), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, (bf16*)dx, n, h, w_, c, relu);
     else hipLaunchKernelGGL((maxpool2_bwd_kernel<bf16, 4>), dim3(g), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, (bf16*)dx, n, h, w_, c, relu);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_maxpool2_bwd_idx(const void* dy, const void* y, const uint32_t* idx, void* dx, int32_t n, int32_t h, int32_t w_, int32_t c,
+                                   int32_t dtype, sp_stream_t stream) {
+    SP_CHECK_ARG(SP_POOL_ARGS_OK(dy, dx, c) && y && idx && h % 2 == 0 && w_ % 2 == 0 && c % 16 == 0, "sp_maxpool2_bwd_idx: bad args");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int v = dtype == SP_BF16 ? 8 : 4;
+    const int g = ew_grid((long)n * (h / 2) * (w_ / 2) * c / v);
+    SP_CHECK_ARG(g > 0, "tensor too large for the 32-bit item index of the resampling kernels");
+    if (dtype == SP_F32) hipLaunchKernelGGL((maxpool2_bwd_idx_kernel<float, 4>), dim3(g), dim3(256), 0, s, (const float*)dy, (const float*)y, idx, (float*)dx, n, h, w_, c);
+    else hipLaunchKernelGGL((maxpool2_bwd_idx_kernel<bf16, 8>), dim3(g), dim3(256), 0, s, (const bf16*)dy, (const bf16*)y, idx, (bf16*)dx, n, h, w_, c);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }

@@ -120,6 +120,8 @@ _FUSE_UPSAMPLE_BN = CFG.fuse_upsample_bn
 _SIDE_FEATURES = CFG.side_features
 # The second generator forward of a step derives its masked-feature mappings from the first one's (Generator._feature_maps_of_the_step).
 _REUSE_FEATURE_MAPS = CFG.reuse_feature_maps
+# VGG-16 pass with gradient: pooled output + window positions instead of the unpooled tensor (_VGGPyramidFn, sp_conv_params.pool_idx).
+_VGG_POOL_IDX = CFG.vgg_pool_idx
 
 
 def init_weights(module: nn.Module) -> None:
@@ -615,7 +617,8 @@ class _VGGPyramidFn(torch.autograd.Function):
         feats = []
         h = w = img.shape[2]
         ci = 0
-        trace = []                 # ('conv', idx_in_acts_of_input, pack) | ('pool', idx_of_input)
+        trace = []                 # ('conv', idx_in_acts_of_input, pack) | ('pool', idx_of_input) | ('poolidx', idx_of_pooled_output, slot, h, w)
+        pool_idx = []              # window positions recorded by the fused ReLU + MaxPool epilogues of the pass with gradient
         # no-gradient pass (features of the real images, model_wrapper.py:139-141): the unpooled output of a stage's last
         # convolution is never looked at again, so its ReLU + MaxPool ride in the convolution's epilogue (pool2 = 2)
         fuse_pool = _FUSE_POOL2 and not ctx.needs_input_grad[0]
@@ -687,6 +690,24 @@ class _VGGPyramidFn(torch.autograd.Function):
                 pk = packs["conv"][ci]
                 ci += 1
                 x8 = None
+                if (ctx.needs_input_grad[0] and _VGG_POOL_IDX and _FUSE_POOL2 and k + 1 < len(_VGG_CFG) and _VGG_CFG[k + 1] == "M"
+                        and ops.conv_pool_idx_ok(n, h, w, x.shape[1], v, dtype)):
+                    # pass WITH gradient (the fake images, model_wrapper.py:179; both groups of a two-group pass), last convolution of a
+                    # stage: ReLU + MaxPool ride in the epilogue and the window position of every maximum is recorded (2 bits per pooled
+                    # element, sp_conv_params.pool_idx) - the unpooled tensor (168 MB at 64 x 256 x 256, batch 20) is neither written,
+                    # nor read by a pooling pass, nor read again by the pooling's backward (sp_maxpool2_bwd_idx)
+                    y = ops.nhwc_empty(n, v, h // 2, w // 2, dtype, dev)
+                    pidx = torch.empty(n * (h // 2) * (w // 2) * (v // 16), dtype=torch.int32, device=dev)
+                    ops.conv_launch(x, pk["fwd"].data_ptr(), pk["bias"], y, None, None, None, 0.0, n, h, w, x.shape[1], v, v, 3, ACT_RELU,
+                                    dtype, pool2=2, k_real=pk["cin"], pool_idx=pidx)
+                    trace.append(("conv", len(acts) - 1, pk))
+                    acts.append(None)                                    # (the unpooled output does not exist)
+                    trace.append(("poolidx", len(acts), len(pool_idx), h, w))
+                    pool_idx.append(pidx)
+                    skip_pool = True
+                    x = y
+                    acts.append(x)
+                    continue
                 if fuse_pool and k + 1 < len(_VGG_CFG) and _VGG_CFG[k + 1] == "M" and ops.conv_pool2_ok(h, w, v, 3):
                     y = ops.nhwc_empty(n, v, h // 2, w // 2, dtype, dev)
                     ops.conv_launch(x, pk["fwd"].data_ptr(), pk["bias"], y, None, None, None, 0.0, n, h, w, x.shape[1], v, v, 3, ACT_RELU,
@@ -742,7 +763,7 @@ class _VGGPyramidFn(torch.autograd.Function):
             f8["calibrated"] = True
         ctx.trace, ctx.packs, ctx.dtype, ctx.hw_last = trace, packs, dtype, (h, w)
         ctx.img_meta = (img.shape, img.dtype)
-        ctx.save_for_backward(*acts, p7, h1, h2)
+        ctx.save_for_backward(*acts, p7, h1, h2, *pool_idx)
         ctx.n_acts = len(acts)
         ctx.n_grad = n_grad
         ops.PROBE_NET[0] = "sn"
@@ -758,7 +779,8 @@ class _VGGPyramidFn(torch.autograd.Function):
         ops.PROBE_NET[0] = "vgg"
         saved = ctx.saved_tensors
         acts = saved[:ctx.n_acts]
-        p7, h1, h2 = saved[ctx.n_acts:]
+        p7, h1, h2 = saved[ctx.n_acts:ctx.n_acts + 3]
+        pool_idx = saved[ctx.n_acts + 3:]
         dtype, packs = ctx.dtype, ctx.packs
         dev = h1.device
         n = ctx.n_grad                    # (two-group pass: the first n images of every saved tensor)
@@ -789,7 +811,22 @@ class _VGGPyramidFn(torch.autograd.Function):
         tap = 4
         folded = False              # the tap gradient of the coming pool step already rode in the dgrad launch that produced g (res1)
         for step in reversed(ctx.trace):
-            if step[0] == "pool":
+            if step[0] == "poolidx":
+                _, yi, slot, h, w = step
+                ypool = acts[yi]
+                c = ypool.shape[1]
+                gt = dfeats[tap] if not folded else None
+                folded = False
+                tap -= 1
+                if gt is not None:
+                    gt = ops.as_nhwc(gt, dtype)
+                    g = gt if g is None else g + gt
+                if g is None:
+                    continue
+                dx = ops.nhwc_empty(n, c, h, w, dtype, dev)
+                Lb.call("sp_maxpool2_bwd_idx", ops.ptr(g), ops.ptr(ypool), ops.ptr(pool_idx[slot]), ops.ptr(dx), n, h, w, c, sd, ops.stream())
+                g = dx
+            elif step[0] == "pool":
                 xin = acts[step[1]]
                 _, c, h, w = xin.shape
                 gt = dfeats[tap] if not folded else None
@@ -818,7 +855,7 @@ class _VGGPyramidFn(torch.autograd.Function):
                 # the input of this convolution is a pyramid tap (a pool output): the tap's own gradient (reconstruction loss) joins the
                 # chain in this launch's epilogue (res1) instead of a separate elementwise addition
                 res1 = None
-                if (not first) and ctx.trace[idx - 1][0] == "pool" and dfeats[tap] is not None and pk["cin"] == cin_p:
+                if (not first) and ctx.trace[idx - 1][0] in ("pool", "poolidx") and dfeats[tap] is not None and pk["cin"] == cin_p:
                     res1 = ops.as_nhwc(dfeats[tap], dtype)
                     folded = True
                 ops.conv_launch(g, pk["dgrad"].data_ptr(), None, dx, res1, None, xin if producer_is_conv else None, 0.0, n, h, w,

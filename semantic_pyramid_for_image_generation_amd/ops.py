@@ -654,15 +654,17 @@ def set_tuning(key: int, value: int) -> None:
 
 def conv_launch(x, w_ptr: int, bias, y, res1, res2, mask_src, slope: float, n, h, w, cin_p, cout, ldy, ksize, act,
                 dtype, pool2: bool = False, in_up2: bool = False, family: str = "fwd", img_scale: int = 0, img_split: int = 0,
-                k_real: Optional[int] = None) -> None:
-    """k_real: the layer's real reduction channels where cin_p counts zero padding (bench.py's FLOP bookkeeping only)."""
+                k_real: Optional[int] = None, pool_idx: Optional[torch.Tensor] = None) -> None:
+    """k_real: the layer's real reduction channels where cin_p counts zero padding (bench.py's FLOP bookkeeping only).
+    pool_idx (with pool2 = 2): int32 tensor that receives the window positions of the maxima (include/sempyr.h)."""
     if KERNEL_PROBE is not None:
         _probed(family, 2.0 * n * h * w * (k_real if k_real is not None else cin_p) * cout * ksize * ksize, _is_halo128(n, h, w, cout, ksize),
                 lambda: _conv_launch(x, w_ptr, bias, y, res1, res2, mask_src, slope, n, h, w, cin_p, cout, ldy, ksize, act, dtype, pool2, in_up2,
-                                     img_scale, img_split),
+                                     img_scale, img_split, pool_idx),
                 (ksize, cin_p, cout, h, w, n))
         return
-    _conv_launch(x, w_ptr, bias, y, res1, res2, mask_src, slope, n, h, w, cin_p, cout, ldy, ksize, act, dtype, pool2, in_up2, img_scale, img_split)
+    _conv_launch(x, w_ptr, bias, y, res1, res2, mask_src, slope, n, h, w, cin_p, cout, ldy, ksize, act, dtype, pool2, in_up2, img_scale, img_split,
+                 pool_idx)
 
 
 def conv_pool2_ok(h: int, w: int, cout: int, ksize: int) -> bool:
@@ -670,10 +672,19 @@ def conv_pool2_ok(h: int, w: int, cout: int, ksize: int) -> bool:
     return ksize == 3 and cout > 32 and cout % 16 == 0 and h % 8 == 0 and w % 32 == 0
 
 
+def conv_pool_idx_ok(n: int, h: int, w: int, cin_p: int, cout: int, dtype) -> bool:
+    """3x3 layers whose following ReLU + MaxPool2d(2) can ride in the epilogue WITH the window positions recorded for the backward pass
+    (include/sempyr.h: sp_conv_params.pool_idx; mirrors the library's admission test)."""
+    esz = 4 if dtype == torch.float32 else 2
+    return (conv_pool2_ok(h, w, cout, 3) and cout % 16 == 0 and n * h * w * cin_p * esz < (1 << 30) and cout * 9 * cin_p * esz < (1 << 30))
+
+
 def _conv_launch(x, w_ptr: int, bias, y, res1, res2, mask_src, slope: float, n, h, w, cin_p, cout, ldy, ksize, act,
-                 dtype, pool2: bool = False, in_up2: bool = False, img_scale: int = 0, img_split: int = 0) -> None:
+                 dtype, pool2: bool = False, in_up2: bool = False, img_scale: int = 0, img_split: int = 0, pool_idx=None) -> None:
     """img_scale: device ADDRESS of the two per-group accumulator scales of a two-group batch (include/sempyr.h), 0 = none."""
     p = L.SpConvParams()
+    if pool_idx is not None:
+        p.pool_idx = pool_idx.data_ptr()
     if img_scale:
         p.img_scale, p.img_split = img_scale, img_split
     p.x, p.w, p.bias, p.y = x.data_ptr(), w_ptr, (bias.data_ptr() if bias is not None else None), y.data_ptr()

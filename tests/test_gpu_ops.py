@@ -622,6 +622,63 @@ def test_maxpool_routing_is_bit_exact_with_ties():
     assert torch.equal(host(xd.grad), x.grad)
 
 
+POOL_IDX_CASES = [  # (cin, cout, n, h, w, ping-pong kernel off): pp<1> | tall<1,16>, halo<64> (h % 16 != 0), pp<2> | tall<2,8>; fp32: tall / halo
+    (64, 64, 2, 32, 32, 0), (64, 64, 2, 32, 32, 1), (64, 64, 2, 24, 32, 0), (128, 128, 2, 16, 32, 0), (128, 256, 3, 8, 64, 1), (64, 128, 2, 32, 64, 0),
+    (16, 80, 1, 16, 32, 0), (16, 48, 1, 16, 32, 1)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("ties", [False, True])
+@pytest.mark.parametrize("case", POOL_IDX_CASES)
+def test_conv_maxpool_epilogue_records_the_window_positions(case, ties, dtype):
+    """conv3x3 -> ReLU -> MaxPool2d(2) with the pooling AND its routing in the convolution's epilogue (sp_conv_params.pool_idx, the
+    frozen VGG-16's stages in the pass with gradient, /root/reference/models.py:183-216): pooled output and the gradient routed by
+    sp_maxpool2_bwd_idx are BIT-IDENTICAL to the separate path (unpooled tensor -> sp_maxpool2_fwd -> sp_maxpool2_bwd with relu,
+    itself pinned to torch's first-maximum routing by test_maxpool_routing_is_bit_exact_with_ties), in every kernel that pools.
+    ties: small-integer operands, so that windows are full of exactly equal values and of all-negative windows."""
+    from semantic_pyramid_for_image_generation_amd import _lib as L
+    cin, cout, n, h, w, pp_off = case
+    ops.set_compute_dtype(dtype)
+    g = torch.Generator().manual_seed(11)
+    if ties:
+        x = torch.randint(0, 2, (n, cin, h, w), generator=g).float()
+        wt = torch.randint(-1, 2, (cout, cin, 3, 3), generator=g).float() * (torch.rand(cout, cin, 3, 3, generator=g) < 0.1).float()
+        bias = torch.randint(-2, 2, (cout,), generator=g).float()
+    else:
+        x, wt, bias = rnd(n, cin, h, w, seed=1), rnd(cout, cin, 3, 3, seed=2) * 0.05, rnd(cout, seed=3)
+    e = ops.chunk_elems(dtype)
+    cin_p = ops.pad_to(cin, e)
+    xd = dev(x, dtype)
+    wd = wt.cuda().contiguous()
+    fwd = torch.empty(cout * 9 * cin_p, dtype=dtype, device="cuda")
+    dg = torch.empty(cin * 9 * ops.pad_to(cout, e), dtype=dtype, device="cuda")
+    sd = ops.sp_dtype(dtype)
+    L.call("sp_pack_weight", ops.ptr(wd), cout, cin * 9, cin, 9, cin_p, ops.pad_to(cout, e), 0, 0, ops.ptr(fwd), ops.ptr(dg), sd, ops.stream())
+    bd = bias.cuda()
+    if pp_off:
+        ops.set_tuning(L.TUNE_KEYS["SP_CONV_PP"], 0)
+    try:
+        full = ops.nhwc_empty(n, cout, h, w, dtype, "cuda")
+        ops.conv_launch(xd, fwd.data_ptr(), bd, full, None, None, None, 0.0, n, h, w, cin_p, cout, cout, 3, ops.ACT_RELU, dtype)
+        pooled = ops.nhwc_empty(n, cout, h // 2, w // 2, dtype, "cuda")
+        idx = torch.full((n * (h // 2) * (w // 2) * (cout // 16),), -1, dtype=torch.int32, device="cuda")
+        ops.conv_launch(xd, fwd.data_ptr(), bd, pooled, None, None, None, 0.0, n, h, w, cin_p, cout, cout, 3, ops.ACT_RELU, dtype, pool2=2,
+                        pool_idx=idx)
+    finally:
+        ops.set_tuning(L.TUNE_KEYS["SP_CONV_PP"], -1)
+    ref_pooled = ops.nhwc_empty(n, cout, h // 2, w // 2, dtype, "cuda")
+    L.call("sp_maxpool2_fwd", ops.ptr(full), ops.ptr(ref_pooled), n, h, w, cout, 0, sd, ops.stream())
+    assert torch.equal(pooled, ref_pooled)
+    gy = dev(rnd(n, cout, h // 2, w // 2, seed=5), dtype)
+    ref_dx, dx = ops.nhwc_empty(n, cout, h, w, dtype, "cuda"), ops.nhwc_empty(n, cout, h, w, dtype, "cuda")
+    L.call("sp_maxpool2_bwd", ops.ptr(gy), ops.ptr(full), ops.ptr(ref_dx), n, h, w, cout, 1, sd, ops.stream())
+    L.call("sp_maxpool2_bwd_idx", ops.ptr(gy), ops.ptr(pooled), ops.ptr(idx), ops.ptr(dx), n, h, w, cout, sd, ops.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(dx, ref_dx)
+    if ties:
+        assert float((ref_dx != 0).float().mean()) > 0.02           # (the case routes something)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_adaptive_avgpool(dtype):
     _fwd_bwd(lambda t: ops.adaptive_avgpool(t, 7, 7), lambda t: F.adaptive_avg_pool2d(t, (7, 7)), rnd(2, 16, 8, 8, seed=1), dtype)

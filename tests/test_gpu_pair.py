@@ -296,6 +296,41 @@ def test_vgg_pyramid_of_two_batches_in_one_pass(dtype, tol):
         ops.set_compute_dtype(torch.float32)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("pair", [False, True])
+def test_vgg_pass_with_gradient_without_the_unpooled_tensors(pair, dtype):
+    """config.CFG.vgg_pool_idx (round 5): in the pass with gradient a stage's last convolution stores the pooled output + the 2-bit
+    window positions of the maxima (sp_conv_params.pool_idx) and the pooling's backward reads those (sp_maxpool2_bwd_idx) - the seven
+    features and the image gradient are BIT-IDENTICAL to the pass that writes the unpooled tensors and pools them separately, alone
+    and as the first group of a two-group pass (/root/reference/models.py:183-216, model_wrapper.py:179)."""
+    import semantic_pyramid_for_image_generation_amd as spm
+    from semantic_pyramid_for_image_generation_amd import models
+    ops.set_compute_dtype(dtype)
+    V = spm.VGG16()
+    _, _, Vsd = gu.synth_states({"cf": 4, "seed": 7})
+    V.load_state_dict(Vsd)
+    V.cuda().eval()
+    g = torch.Generator().manual_seed(5)
+    a = (torch.rand(2, 3, 256, 256, generator=g) * 2 - 1).cuda()
+    b = (torch.rand(2, 3, 256, 256, generator=g) * 2 - 1).cuda()
+    results = []
+    saved = models._VGG_POOL_IDX
+    try:
+        for on in (False, True):
+            models._VGG_POOL_IDX = on
+            x = a.clone().requires_grad_(True)
+            feats = V.forward_pair(x, b)[0] if pair else V(x)
+            seeds = [torch.randn(f.shape, generator=torch.Generator().manual_seed(10 + i)).cuda().to(f.dtype) for i, f in enumerate(feats)]
+            torch.autograd.backward(feats, seeds)
+            results.append(([f.detach().clone() for f in feats], x.grad.clone()))
+    finally:
+        models._VGG_POOL_IDX = saved
+    (f0, g0), (f1, g1) = results
+    for i, (u, v) in enumerate(zip(f0, f1)):
+        assert torch.equal(u, v), ("feature", i)
+    assert torch.equal(g0, g1) and float(g0.abs().max()) > 0
+
+
 def test_train_step_with_the_next_batch_announced_matches_plain_steps():
     """ModelWrapper.train_step(next_images_real=...) (config.CFG.vgg_pair): three iterations over two alternating batches, each
     announcing the next one's real images, against the same iterations without the announcement - fp32, same RNG stream: losses and
