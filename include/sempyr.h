@@ -281,6 +281,11 @@ int sp_sn_backward_batched(const sp_sn_bwd_layer* table_dev, int32_t n_layers, i
 int sp_sn_backward_batched_scaled(const sp_sn_bwd_layer* table_dev, int32_t n_layers, int64_t max_elems, float* arena,
                                   const float* scratch, float* grads, const float* accumulate_from, float* bias_grads,
                                   float* dot_partials, float grad_scale, sp_stream_t stream);
+/* ... and with the factor read from device memory (grad_scale_dev[0]) when the kernel runs: the SP_F16 mode's DYNAMIC loss scale
+ * (sp_loss_scale_update) - a captured graph keeps working while the scale moves. */
+int sp_sn_backward_batched_dscaled(const sp_sn_bwd_layer* table_dev, int32_t n_layers, int64_t max_elems, float* arena,
+                                   const float* scratch, float* grads, const float* accumulate_from, float* bias_grads,
+                                   float* dot_partials, const float* grad_scale_dev, sp_stream_t stream);
 
 /* One-off packing of a frozen, non-normalised fp32 weight (the VGG-16 pyramid, models.py:176-181) into the
  * same two packings.  chw_c > 0: the input-feature index is permuted from NCHW-flatten (c*chw_hw + s) to
@@ -521,6 +526,20 @@ int sp_adam_multi(const sp_adam_chunk* chunks_dev, int32_t n_chunks, double beta
  * network's flat gradient buffer before the optimizer step (the activation gradients of this network - means over 5e4 ... 5e6
  * elements - would be subnormal in fp16 without it; the reference trains in fp32, model_wrapper.py:160,188). */
 int sp_scale_f32(float* x, int64_t numel, float factor, sp_stream_t stream);
+int sp_scale_f32_dev(float* x, int64_t numel, const float* factor_dev, sp_stream_t stream);   /* factor_dev[0] read on the device */
+
+/* Dynamic loss scaling of the SP_F16 storage mode, entirely on the device (no host sync, graph-safe; torch.cuda.amp.GradScaler's
+ * policy - the reference trains in fp32 and needs none, model_wrapper.py:160-162,188-190).  fp16 activation gradients overflow to
+ * inf above 65504 and one such step would poison Adam's moments for good, so per optimizer step:
+ *   sp_check_finite        found[0] = 1 if x holds any inf / NaN (x: a network's flat fp32 gradient buffer, 16-byte aligned; found is
+ *                          only ever set here - sp_loss_scale_update clears it)
+ *   sp_adam_multi_guarded  sp_adam_multi that does NOTHING when skip_if_nonzero[0] != 0 (NULL: plain sp_adam_multi)
+ *   sp_loss_scale_update   state = {scale, 1 / scale, clean steps, found, skipped steps}: found -> scale *= backoff (>= 1), clean = 0,
+ *                          skipped += 1; else clean += 1 and after `interval` clean steps scale *= growth (<= 2^24); found = 0. */
+int sp_check_finite(const float* x, int64_t numel, float* found, sp_stream_t stream);
+int sp_adam_multi_guarded(const sp_adam_chunk* chunks_dev, int32_t n_chunks, double beta1, double beta2, double eps,
+                          double weight_decay, const float* skip_if_nonzero, sp_stream_t stream);
+int sp_loss_scale_update(float* state, float growth, float backoff, int32_t interval, sp_stream_t stream);
 
 #ifdef __cplusplus
 }

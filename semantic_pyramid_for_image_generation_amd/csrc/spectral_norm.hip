@@ -388,7 +388,9 @@ __global__ __launch_bounds__(256) void sn_bwd_dot_batched_kernel(const sp_sn_bwd
 
 __global__ __launch_bounds__(256) void sn_bwd_apply_batched_kernel(const sp_sn_bwd_layer* __restrict__ table, const float* __restrict__ arena,
                                                                    const float* __restrict__ scratch, float* grads, const float* prev,
-                                                                   float* bias_grads, const float* __restrict__ dot_partials, float grad_scale) {
+                                                                   float* bias_grads, const float* __restrict__ dot_partials, float grad_scale,
+                                                                   const float* __restrict__ grad_scale_dev) {
+    if (grad_scale_dev != nullptr) grad_scale = *grad_scale_dev;      // sp_sn_backward_batched_dscaled: the fp16 mode's dynamic loss scale
     const sp_sn_bwd_layer L = table[blockIdx.y];
     if (bias_grads != nullptr && blockIdx.x == 0) {            // bias gradients: plain sums, copied / added as they are
         for (int r = threadIdx.x; r < L.rows; r += 256) {
@@ -578,9 +580,26 @@ extern "C" int sp_sn_backward_batched(const sp_sn_bwd_layer* table_dev, int32_t 
     return sp_sn_backward_batched_scaled(table_dev, n_layers, max_elems, arena, scratch, grads, accumulate_from, bias_grads, dot_partials, 1.0f, stream);
 }
 
+static int sn_backward_batched(const sp_sn_bwd_layer* table_dev, int32_t n_layers, int64_t max_elems, float* arena, const float* scratch, float* grads,
+                               const float* accumulate_from, float* bias_grads, float* dot_partials, float grad_scale, const float* grad_scale_dev,
+                               sp_stream_t stream);
+
 extern "C" int sp_sn_backward_batched_scaled(const sp_sn_bwd_layer* table_dev, int32_t n_layers, int64_t max_elems, float* arena,
                                              const float* scratch, float* grads, const float* accumulate_from, float* bias_grads,
                                              float* dot_partials, float grad_scale, sp_stream_t stream) {
+    return sn_backward_batched(table_dev, n_layers, max_elems, arena, scratch, grads, accumulate_from, bias_grads, dot_partials, grad_scale, nullptr, stream);
+}
+
+extern "C" int sp_sn_backward_batched_dscaled(const sp_sn_bwd_layer* table_dev, int32_t n_layers, int64_t max_elems, float* arena,
+                                              const float* scratch, float* grads, const float* accumulate_from, float* bias_grads,
+                                              float* dot_partials, const float* grad_scale_dev, sp_stream_t stream) {
+    SP_CHECK_ARG(grad_scale_dev != nullptr, "sp_sn_backward_batched_dscaled: null scale pointer");
+    return sn_backward_batched(table_dev, n_layers, max_elems, arena, scratch, grads, accumulate_from, bias_grads, dot_partials, 1.0f, grad_scale_dev, stream);
+}
+
+static int sn_backward_batched(const sp_sn_bwd_layer* table_dev, int32_t n_layers, int64_t max_elems, float* arena, const float* scratch, float* grads,
+                               const float* accumulate_from, float* bias_grads, float* dot_partials, float grad_scale, const float* grad_scale_dev,
+                               sp_stream_t stream) {
     SP_CHECK_ARG(table_dev && arena && scratch && grads && dot_partials && n_layers > 0 && max_elems > 0, "sp_sn_backward_batched: bad args");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int bx = (int)((max_elems + 1023) / 1024);
@@ -588,7 +607,7 @@ extern "C" int sp_sn_backward_batched_scaled(const sp_sn_bwd_layer* table_dev, i
     dim3 grid(bx, n_layers);
     hipLaunchKernelGGL(sn_bwd_dot_batched_kernel, grid, dim3(256), 0, s, table_dev, arena, dot_partials);
     hipLaunchKernelGGL(sn_bwd_apply_batched_kernel, grid, dim3(256), 0, s, table_dev, arena, scratch, grads, accumulate_from, bias_grads,
-                       dot_partials, grad_scale);
+                       dot_partials, grad_scale, grad_scale_dev);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }

@@ -127,7 +127,7 @@ class ModelWrapper(object):
             bank.on_group_done = None
             bank.collect_extra()
             if bank.flat is not None:
-                # fp16 mode: the static loss scale has come off the spectral-normalised layers' gradients inside their batched
+                # fp16 mode: the loss scale has come off the spectral-normalised layers' gradients inside their batched
                 # backward; the tail of the buffer (gradients that arrived through autograd) loses it here (16-byte aligned offset)
                 ops.unscale_(bank.flat, bank.sn_floats)
         elif ops.loss_scale() != 1.0:
@@ -158,6 +158,24 @@ class ModelWrapper(object):
     def _join_reduce(self, tag: str = "") -> None:
         if self.gradient_reducer is not None:
             self.gradient_reducer.join(tag)
+
+    def _optimizer_step(self, key: str, optimizer) -> None:
+        """optimizer.step() - in the fp16 storage mode behind the overflow guard of the dynamic loss scale (ops.LossScaler): the
+        network's flat gradient buffer (already averaged over the ranks, so every rank decides alike) is screened for inf / NaN, the
+        step is skipped where one is found, and the scale is backed off / grown - all on the device for this package's Adam
+        (sp_adam_multi_guarded); a foreign optimizer costs one host sync per step for the same decision."""
+        bank = self._banks.get(key)
+        sc = ops.loss_scaler(bank.flat.device) if bank is not None and bank.flat is not None else None
+        if sc is None:
+            optimizer.step()
+            return
+        from . import optim
+        sc.check(bank.flat)
+        if isinstance(optimizer, optim.Adam):
+            optimizer.step(found_inf=sc.found_ptr)
+        elif not sc.values()["found"]:
+            optimizer.step()
+        sc.update()
 
     # ------------------------------------------------------------------------------------------
     def _d_phase(self, images_real, labels, labels_f, masks, noise_d, features_real=None):
@@ -246,7 +264,7 @@ class ModelWrapper(object):
                         for dst, src in zip(features_next_out, features_next):
                             dst.copy_(src)
                     features_next = features_next_out
-                self._vgg_ahead = (next_images_real, next_images_real._version, features_next)
+                self._vgg_ahead = (next_images_real, next_images_real._version, features_next, self._mode_key())
         finally:
             for p in self._d_params:
                 p.requires_grad_(True)
@@ -255,9 +273,14 @@ class ModelWrapper(object):
     def _features_ahead(self, images_real):
         """The pyramid of images_real if the previous iteration computed it ahead (same tensor object, not written since)."""
         ahead, self._vgg_ahead = self._vgg_ahead, None
-        if ahead is not None and ahead[0] is images_real and ahead[1] == images_real._version:
+        if ahead is not None and ahead[0] is images_real and ahead[1] == images_real._version and ahead[3] == self._mode_key():
             return ahead[2]
         return None
+
+    @staticmethod
+    def _mode_key():
+        """What a pyramid computed ahead depends on beside the images: the storage type and the fp8 slice (round-4 ADVICE)."""
+        return (ops.compute_dtype(), ops.vgg_fp8())
 
     def train_step(self, images_real: torch.Tensor, labels: torch.Tensor, masks, w_rec: float = 0.1, w_div: float = 0.1,
                    noise_d: Optional[torch.Tensor] = None, noise_g: Optional[torch.Tensor] = None,
@@ -275,7 +298,11 @@ class ModelWrapper(object):
         the G phase (independent of D); join; Adam(D); rest of the G phase; [G gradients -> side stream]; join; Adam(G)."""
         # the one-hot labels become class indices ONCE per step (the reference's modules take the argmax in every forward,
         # models.py:151,501: five reductions and a float copy per step; our modules pass indices through)
-        labels = labels_f = _class_index(labels)
+        # - only for this package's modules: a caller's own module may take the argmax of what it is given (round-4 ADVICE)
+        raw_labels = labels
+        idx = _class_index(labels)
+        labels = idx if isinstance(self.discriminator, Discriminator) else raw_labels
+        labels_f = idx if isinstance(self.generator, Generator) else raw_labels
         with profiling.range("D phase"):
             features_real, loss_d_real, loss_d_fake = self._d_phase(images_real, labels, labels_f, masks, noise_d,
                                                                       self._features_ahead(images_real))
@@ -284,13 +311,13 @@ class ModelWrapper(object):
             images_fake, noise_g = self._g_forward(images_real, labels_f, masks, features_real, noise_g)
         with profiling.range("Adam(D)"):
             self._join_reduce("d")
-            self.discriminator_optimizer.step()
+            self._optimizer_step("d", self.discriminator_optimizer)
         with profiling.range("G rest"):
             loss_g, loss_rec, loss_div = self._g_rest(images_fake, noise_g, labels, masks, features_real, w_rec, w_div, next_images_real)
             self._start_reduce("g", self._g_params, eager=True)
         with profiling.range("Adam(G)"):
             self._join_reduce("g")
-            self.generator_optimizer.step()
+            self._optimizer_step("g", self.generator_optimizer)
         self.iterations += 1
         return {"loss_discriminator_real": loss_d_real.detach(), "loss_discriminator_fake": loss_d_fake.detach(),
                 "loss_generator": loss_g.detach(), "loss_generator_semantic_reconstruction": loss_rec.detach().reshape(()),
@@ -318,6 +345,7 @@ class ModelWrapper(object):
         st["flat_ptrs"] = self._flat_ptrs()
         st["images"], st["labels"], st["masks"] = images_real.clone(), labels.clone(), [m.clone() for m in masks]
         st["w"] = (w_rec, w_div)
+        st["mode"] = self._mode_key()
         zdim = (images_real.shape[0], self.latent_dimensions)
         st["noise_d"] = torch.zeros(zdim, dtype=torch.float32, device=images_real.device)
         st["noise_g"] = torch.zeros(zdim, dtype=torch.float32, device=images_real.device)
@@ -339,14 +367,16 @@ class ModelWrapper(object):
             gd = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gd):
                 cls = st["cls"] = _class_index(st["labels"])          # recomputed by every replay of this graph; the other two read it
-                feats, l_real, l_fake = self._d_phase(st["images"], cls, cls, st["masks"], st["noise_d"], st["feats_real"])
+                lab_d = cls if isinstance(self.discriminator, Discriminator) else st["labels"]      # (a caller's own module gets what it was written for)
+                lab_g = cls if isinstance(self.generator, Generator) else st["labels"]
+                feats, l_real, l_fake = self._d_phase(st["images"], lab_d, lab_g, st["masks"], st["noise_d"], st["feats_real"])
             st["d_grads"] = [p.grad for p in self._d_params]
             gf = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gf, pool=gd.pool()):
-                fake, _ = self._g_forward(st["images"], cls, st["masks"], feats, st["noise_g"])
+                fake, _ = self._g_forward(st["images"], lab_g, st["masks"], feats, st["noise_g"])
             gg = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gg, pool=gd.pool()):
-                l_g, l_rec, l_div = self._g_rest(fake, st["noise_g"], cls, st["masks"], feats, w_rec, w_div, st.get("images_next"),
+                l_g, l_rec, l_div = self._g_rest(fake, st["noise_g"], lab_d, st["masks"], feats, w_rec, w_div, st.get("images_next"),
                                                  st["feats_real"])
             st["g_grads"] = [p.grad for p in self._g_params]
         finally:
@@ -404,6 +434,11 @@ class ModelWrapper(object):
                 st["announced"] = (next_images_real, next_images_real._version)
             else:
                 st["announced"] = None
+                if images_real is None and not st["next_is_resident"]:
+                    # back in the resident mode after streamed batches: the batch to take ahead is the resident one again (round-4
+                    # ADVICE: the flag stayed False for good and every later resident replay recomputed its pyramid eagerly)
+                    st["images_next"].copy_(st["images"])
+                    st["next_is_resident"] = True
             # after this call st["feats_real"] holds the pyramid of st["images_next"]: the resident batch's only while both buffers agree
             st["resident_ok"] = st["next_is_resident"]
             if not feats_ok:                                    # nobody computed this batch's pyramid ahead: now, eagerly
@@ -428,7 +463,7 @@ class ModelWrapper(object):
             st["gf"].replay()                                   # generator forward: overlaps the D gradient all-reduce
         with profiling.range("Adam(D)"):
             self._join_reduce("d")
-            self.discriminator_optimizer.step()
+            self._optimizer_step("d", self.discriminator_optimizer)
         with profiling.range("G rest"):
             st["gg"].replay()
             for p, g in zip(self._g_params, st["g_grads"]):
@@ -438,7 +473,7 @@ class ModelWrapper(object):
             self._start_reduce("g", self._g_params, eager=False)
         with profiling.range("Adam(G)"):
             self._join_reduce("g")
-            self.generator_optimizer.step()
+            self._optimizer_step("g", self.generator_optimizer)
         self.iterations += 1
         return st["out"]
 
@@ -474,11 +509,14 @@ class ModelWrapper(object):
                 return self.train_step_graphed(images_real, labels, masks, next_images_real=next_images_real)
             ann = st.get("announced")
             if ann is not None and ann[0] is images_real and ann[1] == images_real._version:
-                self._vgg_ahead = (images_real, ann[1], st["feats_real"])       # computed ahead by the last replay
+                self._vgg_ahead = (images_real, ann[1], st["feats_real"], st.get("mode"))       # computed ahead by the last replay
             st["announced"] = None
         out = self.train_step(images_real, labels, masks, w_rec=w_rec, w_div=w_div, next_images_real=next_images_real)
-        if st is not None and st.get("sig") == sig:
-            return out                                          # (an eager iteration under a valid capture: nothing to re-capture)
+        if st is not None and st.get("sig") == sig and st.get("w") == (w_rec, w_div) and next_images_real is None:
+            return out                                          # (an epoch's last iteration under a valid capture: nothing to re-capture)
+        if st is not None and st.get("sig") == sig and st.get("w") != (w_rec, w_div):
+            st = self._graph_state = None                       # other loss weights than the captured ones: capture again (round-4 ADVICE)
+            self._eager_run = 0
         if after and after > 0 and images_real.is_cuda and not self._graph_failed:
             self._eager_run = self._eager_run + 1 if sig == self._eager_sig else 1
             self._eager_sig = sig

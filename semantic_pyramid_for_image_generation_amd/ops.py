@@ -38,40 +38,87 @@ def is_16bit(dtype: torch.dtype) -> bool:
 
 
 def loss_scale() -> float:
-    """Static factor on the loss gradient in the fp16 mode (config.CFG.f16_loss_scale, default 2^16); 1.0 otherwise."""
+    """The fp16 mode's INITIAL loss scale (config.CFG.f16_loss_scale, default 2^16; set_loss_scale); 1.0 outside the fp16 mode - and 1.0
+    means "no scaling".  The scale in force lives on the device and moves (loss_scaler)."""
     return float(_STATE["loss_scale"]) if _STATE["dtype"] == torch.float16 else 1.0
 
 
-def set_loss_scale(value: float) -> None:
+def set_loss_scale(value: float, growth: float = 2.0, backoff: float = 0.5, growth_interval: int = 2000) -> None:
+    """(Re)starts the fp16 mode's loss scale at `value` (1.0 switches scaling off) with torch.cuda.amp.GradScaler's policy: an
+    optimizer step whose gradients hold an inf / NaN is skipped and the scale multiplied by `backoff`; after `growth_interval`
+    clean optimizer steps it is multiplied by `growth`."""
     _STATE["loss_scale"] = float(value)
+    _STATE["ls_policy"] = (float(growth), float(backoff), int(growth_interval))
+    _SCALERS.clear()
+
+
+class LossScaler:
+    """Device state of the dynamic loss scale: {scale, 1 / scale, clean steps, non-finite found, steps skipped} (include/sempyr.h:
+    sp_loss_scale_update).  Everything that uses the scale reads it from device memory when its kernel RUNS - the seeds of
+    .backward() are views of state[0], the batched spectral-norm backward and the unscale pass take a pointer to state[1] - so a
+    captured graph follows the scale without a re-capture and nothing ever syncs with the host (round-4 ADVICE: the static 2^16
+    had no overflow check - one inf in an fp16 activation gradient would have poisoned Adam's moments for good)."""
+
+    def __init__(self, device, scale: float):
+        self.state = torch.tensor([scale, 1.0 / scale, 0.0, 0.0, 0.0], dtype=torch.float32, device=device)
+
+    @property
+    def inv_ptr(self):
+        return ctypes.c_void_p(self.state.data_ptr() + 4)
+
+    @property
+    def found_ptr(self):
+        return ctypes.c_void_p(self.state.data_ptr() + 12)
+
+    def check(self, flat: torch.Tensor) -> None:
+        """found |= any non-finite value in `flat` (a network's flat gradient buffer, after the all-reduce where there is one)."""
+        L.call("sp_check_finite", ptr(flat), flat.numel(), self.found_ptr, stream())
+
+    def update(self) -> None:
+        growth, backoff, interval = _STATE.get("ls_policy", (2.0, 0.5, 2000))
+        L.call("sp_loss_scale_update", ptr(self.state), growth, backoff, interval, stream())
+
+    def values(self) -> dict:
+        """Host copy (syncs): for tests and reports."""
+        s = self.state.tolist()
+        return {"scale": s[0], "clean_steps": int(s[2]), "found": bool(s[3]), "skipped_steps": int(s[4])}
+
+
+_SCALERS = {}
+
+
+def loss_scaler(device) -> Optional[LossScaler]:
+    """The dynamic loss scale of `device` (fp16 mode with scaling on), else None."""
+    s = loss_scale()
+    if s == 1.0:
+        return None
+    key = str(torch.device(device))
+    sc = _SCALERS.get(key)
+    if sc is None:
+        sc = _SCALERS[key] = LossScaler(device, s)
+    return sc
 
 
 _SCALE_SEED = {}
 
 
-def loss_scale_seed(device) -> Optional[torch.Tensor]:
-    """The `gradient=` argument of .backward() that carries the loss scale (a cached 0-dim tensor: no kernel), or None."""
-    s = loss_scale()
-    if s == 1.0:
-        return None
-    key = (str(device), s)
-    t = _SCALE_SEED.get(key)
-    if t is None:
-        t = _SCALE_SEED[key] = torch.full((), s, dtype=torch.float32, device=device)
-    return t
-
-
 def backward_seeds(losses) -> List[torch.Tensor]:
-    """grad_tensors for torch.autograd.backward(losses, ...): d(sum of the losses) / d(loss) = 1 (times the fp16 mode's static loss
-    scale) per loss, as cached tensors of each loss's shape - summing the losses first and letting autograd make its own seed costs
-    an add per loss, a fill and a reduction wherever the shapes differ (five tiny launches in the generator step)."""
-    s = loss_scale()
+    """grad_tensors for torch.autograd.backward(losses, ...): d(sum of the losses) / d(loss) = 1 (times the fp16 mode's loss scale)
+    per loss, as cached tensors of each loss's shape - summing the losses first and letting autograd make its own seed costs an add per
+    loss, a fill and a reduction wherever the shapes differ (five tiny launches in the generator step).  fp16 mode: views of the
+    device-resident scale (the losses are scalars / one-element tensors), so the seeds follow the dynamic scale."""
     out = []
     for t in losses:
-        key = (str(t.device), s, tuple(t.shape))
+        sc = loss_scaler(t.device)
+        if sc is not None:
+            if t.numel() != 1:
+                raise L.SempyrError("the fp16 mode's loss scale seeds scalar losses only (got shape %s)" % (tuple(t.shape),))
+            out.append(sc.state[0:1].reshape(t.shape))
+            continue
+        key = (str(t.device), tuple(t.shape))
         seed = _SCALE_SEED.get(key)
         if seed is None:
-            seed = _SCALE_SEED[key] = torch.full(tuple(t.shape), s, dtype=torch.float32, device=t.device)
+            seed = _SCALE_SEED[key] = torch.ones(tuple(t.shape), dtype=torch.float32, device=t.device)
         out.append(seed)
     return out
 
@@ -88,12 +135,12 @@ def _loss_acc(device) -> torch.Tensor:
 
 
 def unscale_(flat: torch.Tensor, start: int = 0) -> None:
-    """flat[start:] *= 1 / loss_scale(), in place, one launch of the library (no-op outside the fp16 mode).  The spectral-normalised
-    layers' gradients lose the scale inside the batched backward (sp_sn_backward_batched_scaled); this is for the tail of a bank's
-    buffer - the few parameters whose gradients arrive through autograd (ops.SpectralNormBank.collect_extra)."""
-    s = loss_scale()
-    if s != 1.0 and flat.numel() > start:
-        L.call("sp_scale_f32", ctypes.c_void_p(flat.data_ptr() + 4 * start), flat.numel() - start, 1.0 / s, stream())
+    """flat[start:] *= 1 / (the loss scale in force), in place, one launch of the library (no-op outside the fp16 mode).  The
+    spectral-normalised layers' gradients lose the scale inside the batched backward (sp_sn_backward_batched_dscaled); this is for the
+    tail of a bank's buffer - the few parameters whose gradients arrive through autograd (ops.SpectralNormBank.collect_extra)."""
+    sc = loss_scaler(flat.device)
+    if sc is not None and flat.numel() > start:
+        L.call("sp_scale_f32_dev", ctypes.c_void_p(flat.data_ptr() + 4 * start), flat.numel() - start, sc.inv_ptr, stream())
 
 
 def compute_dtype() -> torch.dtype:
@@ -288,9 +335,14 @@ class _SNBankFn(torch.autograd.Function):
             # parameters' .grad are views of it - autograd neither sums nor stores anything for these parameters
             bank.enter_backward(call.arena.device, g)
             prev = bank.flat if bank.group_count[g] > 0 else None
-            # (fp16 mode: the loss scale comes off right here, where the fp32 parameter gradients are formed)
-            L.call("sp_sn_backward_batched_scaled", table, n, bank.max_elems, ptr(call.arena), ptr(call.scratch),
-                   ptr(bank.flat), ptr(prev), ptr(bank.flat), ptr(dots), 1.0 / loss_scale(), stream())
+            # (fp16 mode: the loss scale in force comes off right here, where the fp32 parameter gradients are formed)
+            sc = loss_scaler(call.arena.device)
+            if sc is not None:
+                L.call("sp_sn_backward_batched_dscaled", table, n, bank.max_elems, ptr(call.arena), ptr(call.scratch),
+                       ptr(bank.flat), ptr(prev), ptr(bank.flat), ptr(dots), sc.inv_ptr, stream())
+            else:
+                L.call("sp_sn_backward_batched_scaled", table, n, bank.max_elems, ptr(call.arena), ptr(call.scratch),
+                       ptr(bank.flat), ptr(prev), ptr(bank.flat), ptr(dots), 1.0, stream())
             bank.group_count[g] += 1
             for i in range(lo, hi):
                 m = bank.specs[i][0]

@@ -96,7 +96,10 @@ class Adam(torch.optim.Adam):
         return plan
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, found_inf=None):
+        """found_inf (optional, the fp16 mode's ops.LossScaler): a device float; the launch updates NOTHING when it is non-zero
+        (sp_adam_multi_guarded) - the step is skipped on the device, without a host sync.  (The host-side step count that feeds the
+        bias corrections still advances on a skipped step; torch's fused Adam takes it back.)"""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -139,5 +142,8 @@ class Adam(torch.optim.Adam):
                 ev = torch.cuda.Event()
                 ev.record()
                 slot[1] = ev
-                L.call("sp_adam_multi", ptr(tab_dev), plan.total, float(b1), float(b2), eps, wd, stream())
+                if found_inf is not None:
+                    L.call("sp_adam_multi_guarded", ptr(tab_dev), plan.total, float(b1), float(b2), eps, wd, found_inf, stream())
+                else:
+                    L.call("sp_adam_multi", ptr(tab_dev), plan.total, float(b1), float(b2), eps, wd, stream())
         return loss

@@ -74,8 +74,8 @@ def training_masks_device(batch_size: int, device, generator: Optional[torch.Gen
     levels; everything deeper than the stage is zero; values are exact 0.0 / 1.0.  ``seed``: the 64-bit seed of this batch
     (the kernel is counter based: no device RNG state, no host sync).  Without it one 63-bit draw is taken from ``generator``
     (a CPU generator: no device sync; re-seeding it restarts the mask sequence, and its state travels with it - round-3 ADVICE:
-    a module-level counter keyed by id(generator) did neither); without a generator, from torch's default CPU generator mixed with
-    the process's RANK, so that the ranks of a data-parallel job draw different masks."""
+    a module-level counter keyed by id(generator) did neither); without a generator, from a module-private generator seeded once
+    from torch.initial_seed() and the process group's rank (_private_generator)."""
     import ctypes
     from . import _lib as L
     from . import ops
@@ -83,15 +83,35 @@ def training_masks_device(batch_size: int, device, generator: Optional[torch.Gen
     if dev.type != "cuda":
         raise L.SempyrError("training_masks_device: needs a CUDA/HIP device (no CPU path; tests use the oracle's restatement)")
     if seed is None:
-        import os
         if generator is not None and generator.device.type != "cpu":
             raise L.SempyrError("training_masks_device: pass a CPU torch.Generator (a device generator would cost a host sync per batch)")
-        draw = int(torch.randint(0, (1 << 63) - 1, (1,), dtype=torch.int64, generator=generator))
-        rank = int(os.environ.get("RANK", "0")) if generator is None else 0
-        seed = (draw + rank * 0x9E3779B97F4A7C15) & ((1 << 64) - 1)
+        if generator is None:
+            generator = _private_generator()
+        seed = int(torch.randint(0, (1 << 63) - 1, (1,), dtype=torch.int64, generator=generator))
     out = [torch.empty((batch_size,) + shp, dtype=torch.float32, device=dev) for shp in MASK_SHAPES]
     L.call("sp_training_masks", *[ops.ptr(t) for t in out], batch_size, ctypes.c_uint64(seed), float(p_random_mask), ops.stream())
     return out
+
+
+_PRIVATE_GEN = [None]
+
+
+def _private_generator() -> torch.Generator:
+    """The module's own CPU generator for callers that pass none: seeded ONCE from torch.initial_seed() and the rank of the process
+    group (torch.distributed when initialised, so that the ranks of a data-parallel job draw different masks) - drawing from torch's
+    global generator on every batch perturbed every other consumer of it: DataLoader seeds, shuffling, user code (round-4 ADVICE)."""
+    if _PRIVATE_GEN[0] is None:
+        rank = 0
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                rank = dist.get_rank()
+        except Exception:
+            rank = 0
+        g = torch.Generator(device="cpu")
+        g.manual_seed((torch.initial_seed() + rank * 0x9E3779B97F4A7C15) & ((1 << 63) - 1))
+        _PRIVATE_GEN[0] = g
+    return _PRIVATE_GEN[0]
 
 
 def bernoulli_masks(g: torch.Generator, p: float = 0.5) -> List[torch.Tensor]:

@@ -1,6 +1,6 @@
 """BASELINE.json config 5's storage type: SP_F16 (IEEE half activations / packed weights, v_mfma_f32_16x16x32_f16, fp32 accumulate;
-the kernel set compiled a second time with -DSP_H16_FP16, csrc/common.h) with a static loss scale on the activation gradients
-(ops.loss_scale, ModelWrapper) - alone, and with the e4m3 / fp8-MFMA slice of the VGG-16 pyramid on top (ops.set_vgg_fp8).
+the kernel set compiled a second time with -DSP_H16_FP16, csrc/common.h) with a dynamic loss scale on the activation gradients
+(ops.LossScaler, ModelWrapper._optimizer_step) - alone, and with the e4m3 / fp8-MFMA slice of the VGG-16 pyramid on top (ops.set_vgg_fp8).
 
 The reference computes in fp32 (/root/reference/model_wrapper.py:148,169); tolerances here are RESTATED and MEASURED (2x the
 measurement, printed on every run): fp16 keeps 11 significant bits against bf16's 8, and the golden-step errors drop about
@@ -152,6 +152,91 @@ def test_f16_gradients_follow_fp32_and_need_the_loss_scale():
         assert rec["scaled_" + key]["cos"] >= 0.9995, rec
         assert rec["scaled_" + key]["norm_rel"] <= 2e-3, rec
         assert rec["scaled_" + key]["cos"] >= rec["bf16_" + key]["cos"] - 1e-4, rec          # never worse than the bf16 mode
+
+
+@pytest.mark.parametrize("own_adam", [True, False])
+def test_f16_overflow_skips_the_step_and_backs_the_scale_off(own_adam):
+    """Round-4 ADVICE (medium): the static 2^16 had no overflow check - one inf in an fp16 activation gradient reached Adam's moments
+    and stayed.  Now (ops.LossScaler, sp_check_finite / sp_adam_multi_guarded / sp_loss_scale_update): a scale far too large makes
+    the gradients overflow; every such optimizer step must leave the parameters AND the moments bit-for-bit untouched and halve the
+    scale, on the device, until the steps come through finite - with this package's Adam (guarded launch, no host sync) and with
+    plain torch.optim.Adam (the front door's optimizer: one host read of the flag)."""
+    import semantic_pyramid_for_image_generation_amd as sp
+    meta, arr = gu.load("step_cf4_b4_seed1")
+    ops.set_compute_dtype(torch.float16)
+    ops.set_loss_scale(2.0 ** 40, growth_interval=3)
+    G, D, V = S.build(meta)
+    adam = sp.optim.Adam if own_adam else torch.optim.Adam
+    opt_g, opt_d = adam(G.parameters(), lr=meta["lr"]), adam(D.parameters(), lr=meta["lr"])
+    mw = sp.ModelWrapper(generator=G, discriminator=D, vgg16=V, training_dataset=None, validation_dataset=None, generator_optimizer=opt_g,
+                         discriminator_optimizer=opt_d, save_data_path=None)
+    G.train(); D.train()
+    images, labels, masks = gu.golden_batches(meta["batch_size"], meta["seed"])[0]
+    images, labels, masks = images.cuda(), labels.cuda(), [m.cuda() for m in masks]
+    before = [p.detach().clone() for p in list(G.parameters()) + list(D.parameters())]
+    out = mw.train_step(images, labels, masks)
+    sc = ops.loss_scaler("cuda:%d" % torch.cuda.current_device())
+    v = sc.values()
+    assert v["skipped_steps"] == 2 and v["scale"] == 2.0 ** 38 and not v["found"], v          # D's step and G's step, one halving each
+    after = list(G.parameters()) + list(D.parameters())
+    assert all(torch.equal(a, b) for a, b in zip(before, after))                             # nothing moved
+    for opt in (opt_g, opt_d):
+        for st in opt.state.values():
+            assert float(st["exp_avg"].abs().max()) == 0.0 and float(st["exp_avg_sq"].abs().max()) == 0.0
+    for _ in range(20):                                                                       # the scale walks down until a step is clean
+        out = mw.train_step(images, labels, masks)
+        if sc.values()["skipped_steps"] < 2 * (_ + 2):
+            break
+    v = sc.values()
+    assert 1.0 < v["scale"] < 2.0 ** 38, v
+    moved = sum(int(not torch.equal(a, b)) for a, b in zip(before, list(G.parameters()) + list(D.parameters())))
+    assert moved > 0
+    assert all(bool(torch.isfinite(p).all()) for p in list(G.parameters()) + list(D.parameters()))
+    for opt in (opt_g, opt_d):
+        assert all(bool(torch.isfinite(st["exp_avg"]).all()) and bool(torch.isfinite(st["exp_avg_sq"]).all()) for st in opt.state.values())
+    assert all(bool(torch.isfinite(out[n]).all()) for n in S.LOSS_NAMES)
+    # growth: after `growth_interval` clean optimizer steps in a row the scale doubles
+    s0 = sc.values()["scale"]
+    seen = [s0]
+    for _ in range(4):
+        mw.train_step(images, labels, masks)
+        seen.append(sc.values()["scale"])
+    assert max(seen) >= 2.0 * min(seen[:2]) or sc.values()["skipped_steps"] > v["skipped_steps"], seen
+
+
+def test_f16_graph_replay_follows_the_dynamic_scale():
+    """The captured step reads the loss scale from device memory (the seeds of .backward() are views of it, the unscale passes take a
+    pointer): a replay under a scale that has moved since the capture gives what the eager step gives under that scale."""
+    import semantic_pyramid_for_image_generation_amd as sp
+    meta, arr = gu.load("step_cf4_b4_seed1")
+    ops.set_compute_dtype(torch.float16)
+    images, labels, masks = gu.golden_batches(meta["batch_size"], meta["seed"])[0]
+    images, labels, masks = images.cuda(), labels.cuda(), [m.cuda() for m in masks]
+    noise = torch.from_numpy(arr["noise"]).cuda()
+    results = []
+    for graphed in (False, True):
+        ops.set_loss_scale(65536.0)
+        G, D, V = S.build(meta)
+        mw = sp.ModelWrapper(generator=G, discriminator=D, vgg16=V, training_dataset=None, validation_dataset=None,
+                             generator_optimizer=sp.optim.Adam(G.parameters(), lr=meta["lr"]),
+                             discriminator_optimizer=sp.optim.Adam(D.parameters(), lr=meta["lr"]), save_data_path=None)
+        G.train(); D.train()
+        mw.train_step(images, labels, masks, noise_d=noise[0], noise_g=noise[1], next_images_real=images)
+        if graphed:
+            mw.capture_graphs(images, labels, masks)
+        sc = ops.loss_scaler(images.device)
+        sc.state[0:2].copy_(torch.tensor([1024.0, 1.0 / 1024.0], device=images.device))       # the scale moves AFTER the capture
+        if graphed:
+            out = mw.train_step_graphed(images, labels, masks, noise_d=noise[2], noise_g=noise[3], next_images_real=images)
+        else:
+            out = mw.train_step(images, labels, masks, noise_d=noise[2], noise_g=noise[3], next_images_real=images)
+        results.append(({n: float(out[n]) for n in S.LOSS_NAMES}, [p.detach().clone() for p in G.parameters()]))
+    (l0, p0), (l1, p1) = results
+    for n in S.LOSS_NAMES:
+        assert l1[n] == pytest.approx(l0[n], rel=2e-3, abs=1e-6), n
+    num = sum(float((a - b).double().pow(2).sum()) for a, b in zip(p0, p1))
+    den = sum(float(a.double().pow(2).sum()) for a in p0)
+    assert (num / den) ** 0.5 <= 1e-4
 
 
 # fp16 storage + the e4m3 slice of the VGG-16 pyramid (no-gradient pass): BASELINE.json config 5 as built

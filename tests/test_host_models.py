@@ -171,3 +171,20 @@ def test_train_loop_fetches_one_batch_ahead():
         assert [float(g[0].flatten()[0]) for g in got] == [0.0, 1.0, 2.0, 3.0] and all(g[3] is None for g in got)
     finally:
         mwm.CFG.vgg_pair = old
+
+
+def test_device_mask_seeds_leave_the_global_generator_alone():
+    """Round-4 ADVICE: without a caller's generator the device-mask seeds come from a module-private CPU generator (seeded once from
+    torch.initial_seed() and the rank), not from torch's global one - whose stream DataLoader seeds and user code also consume."""
+    from semantic_pyramid_for_image_generation_amd import synthetic
+    torch.manual_seed(1234)
+    synthetic._PRIVATE_GEN[0] = None
+    before = torch.get_rng_state()
+    g = synthetic._private_generator()
+    draws = [int(torch.randint(0, (1 << 63) - 1, (1,), dtype=torch.int64, generator=g)) for _ in range(3)]
+    assert torch.equal(before, torch.get_rng_state())
+    assert synthetic._private_generator() is g and len(set(draws)) == 3
+    synthetic._PRIVATE_GEN[0] = None
+    g2 = synthetic._private_generator()                         # same initial seed -> same mask sequence
+    assert int(torch.randint(0, (1 << 63) - 1, (1,), dtype=torch.int64, generator=g2)) == draws[0]
+    synthetic._PRIVATE_GEN[0] = None
