@@ -22,6 +22,7 @@ results beyond floating-point summation order.  The kernel library itself reads 
     reuse_feature_maps    SP_REUSE_FEATURE_MAPS  1        the generator's masked-feature mappings of the G step derived from the D step's forward (same inputs, same weights, other sigma)
     vgg_pair              SP_VGG_PAIR            1        the VGG-16 pyramid of the NEXT batch's real images rides in the generator step's pass over the fake images (one pass over 2B images; ModelWrapper.train_step(next_images_real=...))
     vgg_pool_idx          SP_VGG_POOL_IDX        1        VGG-16 pass WITH gradient: a stage's last convolution stores the pooled output + 2-bit window positions instead of the unpooled tensor (sp_conv_params.pool_idx)
+    g_pair                SP_G_PAIR              1        the generator's two forwards of an iteration (D step: no gradient; G step: with) as one two-group pass below 256 x 256 (models.Generator.forward_pair); off while a gradient reducer is active (the G-step forward is what hides D's all-reduce)
     f16_loss_scale        SP_F16_LOSS_SCALE      65536    static loss scale of the fp16 storage mode (ops.set_compute_dtype(torch.float16))
     vgg_fp8               SP_VGG_FP8             0        BASELINE.json config 5's fp8 slice: VGG-16's wide 3x3 layers on the fp8 MFMA in the no-gradient pass (ops.set_vgg_fp8)
     lib_path              SEMPYR_LIB             (in-tree libsempyr.so)
@@ -56,6 +57,7 @@ class Config:
     reuse_feature_maps: bool = True
     vgg_pair: bool = True
     vgg_pool_idx: bool = True
+    g_pair: bool = True
 
     @classmethod
     def from_env(cls) -> "Config":
@@ -67,7 +69,7 @@ class Config:
                    side_features=_flag("SP_SIDE_FEATURES", False),
                    fuse_upsample_bn=_flag("SP_FUSE_UPSAMPLE_BN", True), fuse_tail=_flag("SP_FUSE_TAIL", True),
                    wgrad_side_stream=int(os.environ.get("SP_WGRAD_SIDE_STREAM", "0")), reuse_feature_maps=_flag("SP_REUSE_FEATURE_MAPS", True), vgg_pair=_flag("SP_VGG_PAIR", True),
-                   vgg_pool_idx=_flag("SP_VGG_POOL_IDX", True))
+                   vgg_pool_idx=_flag("SP_VGG_POOL_IDX", True), g_pair=_flag("SP_G_PAIR", True))
 
 
 CFG = Config.from_env()

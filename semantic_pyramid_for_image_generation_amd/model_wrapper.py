@@ -10,7 +10,8 @@ What differs from the reference, without changing any observable result (SURVEY.
   * multi-GPU is one process per GPU with an RCCL all-reduce of the gradients (``distributed.GradientReducer``)
     instead of single-process nn.DataParallel (main.py:91-94).
 Validation (FID with a downloaded Inception-v3) and the sample-grid plots are outside the hot path
-(SURVEY.md section 2, rows 8-9): ``validate`` returns nan, ``inference`` stores the generated batch as a .pt file.
+(SURVEY.md section 2, rows 8-9): ``validate`` returns nan; ``inference`` writes the reference's 7 x 7 sample grid as a PNG
+(misc.save_image_grid - torchvision is not a dependency).
 """
 from __future__ import annotations
 
@@ -94,6 +95,9 @@ class ModelWrapper(object):
         self._eager_run, self._eager_sig, self._graph_failed = 0, None, False
         # (real images tensor, its ._version, its VGG pyramid) where the previous iteration computed it ahead (train_step: next_images_real)
         self._vgg_ahead = None
+        # (fake images of the generator step with their autograd graph, their latents) where the discriminator phase has already taken
+        # that forward together with its own (_d_phase: Generator.forward_pair)
+        self._fake_ahead = None
         self._capturing = False
         self._fired = set()
         self.iterations = 0
@@ -178,17 +182,32 @@ class ModelWrapper(object):
         sc.update()
 
     # ------------------------------------------------------------------------------------------
-    def _d_phase(self, images_real, labels, labels_f, masks, noise_d, features_real=None):
+    def _g_pair_ok(self) -> bool:
+        """Both generator forwards of the iteration in one pass (config.CFG.g_pair): this package's generator in training mode, and no
+        gradient reducer at work - under data parallelism the generator-step forward is what the discriminator's all-reduce hides
+        behind (distributed.py), and taking it early would expose that transfer."""
+        return (CFG.g_pair and isinstance(self.generator, Generator) and self.generator.training and not self._reducer_active())
+
+    def _d_phase(self, images_real, labels, labels_f, masks, noise_d, features_real=None, noise_g=None):
         """model_wrapper.py:136-160: forward passes and backward of the discriminator step (everything but Adam).  features_real: the
-        pyramid of images_real where an earlier generator step has already computed it (_g_rest, next_images_real)."""
+        pyramid of images_real where an earlier generator step has already computed it (_g_rest, next_images_real).  noise_g: the
+        latents of the generator step, for the case that its forward is taken in the same pass as this step's (_g_pair_ok)."""
         G, D, V = self.generator, self.discriminator, self.vgg16
         G.zero_grad()
         D.zero_grad()
+        self._fake_ahead = None
         with torch.no_grad():
             if features_real is None:
                 features_real = V(images_real)
             if noise_d is None:
                 noise_d = torch.randn((images_real.shape[0], self.latent_dimensions), dtype=torch.float32, device=images_real.device)
+        if self._g_pair_ok():
+            if noise_g is None:                       # (the reference draws it later, model_wrapper.py:168 - nothing else draws in between)
+                noise_g = torch.randn((images_real.shape[0], self.latent_dimensions), dtype=torch.float32, device=images_real.device)
+            images_fake_g, images_fake = G.forward_pair(noise_g, noise_d, features_real, masks, labels_f)
+            self._fake_ahead = (images_fake_g, noise_g)
+        else:
+          with torch.no_grad():
             if hasattr(G, "map_mode"):
                 G.map_mode = "stash"                  # this forward and the G step's see the same pyramid, masks and weights
             images_fake = G(input=noise_d, features=features_real, masks=masks, class_id=labels_f)
@@ -209,6 +228,9 @@ class ModelWrapper(object):
         all-reduce and D's Adam step may still be in flight / pending while it runs (train_step)."""
         G = self.generator
         G.zero_grad()
+        ahead, self._fake_ahead = self._fake_ahead, None
+        if ahead is not None:                         # taken in the discriminator phase's pass (Generator.forward_pair)
+            return ahead
         if noise_g is None:
             noise_g = torch.randn((images_real.shape[0], self.latent_dimensions), dtype=torch.float32, device=images_real.device)
         if hasattr(G, "map_mode"):
@@ -305,7 +327,7 @@ class ModelWrapper(object):
         labels_f = idx if isinstance(self.generator, Generator) else raw_labels
         with profiling.range("D phase"):
             features_real, loss_d_real, loss_d_fake = self._d_phase(images_real, labels, labels_f, masks, noise_d,
-                                                                      self._features_ahead(images_real))
+                                                                      self._features_ahead(images_real), noise_g)
             self._start_reduce("d", self._d_params, eager=True)
         with profiling.range("G forward"):
             images_fake, noise_g = self._g_forward(images_real, labels_f, masks, features_real, noise_g)
@@ -369,10 +391,15 @@ class ModelWrapper(object):
                 cls = st["cls"] = _class_index(st["labels"])          # recomputed by every replay of this graph; the other two read it
                 lab_d = cls if isinstance(self.discriminator, Discriminator) else st["labels"]      # (a caller's own module gets what it was written for)
                 lab_g = cls if isinstance(self.generator, Generator) else st["labels"]
-                feats, l_real, l_fake = self._d_phase(st["images"], lab_d, lab_g, st["masks"], st["noise_d"], st["feats_real"])
+                feats, l_real, l_fake = self._d_phase(st["images"], lab_d, lab_g, st["masks"], st["noise_d"], st["feats_real"], st["noise_g"])
             st["d_grads"] = [p.grad for p in self._d_params]
-            gf = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gf, pool=gd.pool()):
+            if self._fake_ahead is not None:
+                # the generator-step forward rode in the discriminator phase's pass: nothing is left for a graph of its own
+                gf = None
+                fake, _ = self._g_forward(st["images"], lab_g, st["masks"], feats, st["noise_g"])
+            else:
+              gf = torch.cuda.CUDAGraph()
+              with torch.cuda.graph(gf, pool=gd.pool()):
                 fake, _ = self._g_forward(st["images"], lab_g, st["masks"], feats, st["noise_g"])
             gg = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gg, pool=gd.pool()):
@@ -382,6 +409,7 @@ class ModelWrapper(object):
         finally:
             self._capturing = False
             self._vgg_ahead = None
+            self._fake_ahead = None
         if handed_over is not None and st["feats_real"] is not None and handed_over[0]._version == handed_over[1]:
             with torch.no_grad():                               # ... the first replay finds that batch's pyramid as the eager loop would
                 for dst, src in zip(st["feats_real"], handed_over[2]):
@@ -419,6 +447,11 @@ class ModelWrapper(object):
             st["noise_d"].normal_()
         else:
             st["noise_d"].copy_(noise_d)
+        if st["gf"] is None:                                    # both generator forwards run in the first graph: it needs both draws
+            if noise_g is None:
+                st["noise_g"].normal_()
+            else:
+                st["noise_g"].copy_(noise_g)
         ahead = st.get("feats_real") is not None
         feats_ok = ahead and st["resident_ok"]                  # resident batch: its pyramid is what the last replay left behind
         if images_real is not None and images_real is not st["images"]:
@@ -455,12 +488,13 @@ class ModelWrapper(object):
             for p, g in zip(self._d_params, st["d_grads"]):
                 p.grad = g
             self._start_reduce("d", self._d_params, eager=False)
-        if noise_g is None:
-            st["noise_g"].normal_()
-        else:
-            st["noise_g"].copy_(noise_g)
-        with profiling.range("G forward"):
-            st["gf"].replay()                                   # generator forward: overlaps the D gradient all-reduce
+        if st["gf"] is not None:
+            if noise_g is None:
+                st["noise_g"].normal_()
+            else:
+                st["noise_g"].copy_(noise_g)
+            with profiling.range("G forward"):
+                st["gf"].replay()                               # generator forward: overlaps the D gradient all-reduce
         with profiling.range("Adam(D)"):
             self._join_reduce("d")
             self._optimizer_step("d", self.discriminator_optimizer)
@@ -632,24 +666,32 @@ class ModelWrapper(object):
 
     @torch.no_grad()
     def inference(self, device: str = 'cuda') -> None:
-        """Sample grid of model_wrapper.py:247-296, stored as a tensor file (torchvision is not a dependency)."""
+        """model_wrapper.py:247-296: 7 validation images x the 7 single-stage mask sets (misc.get_masks_for_inference), one fake image
+        each from a fresh latent, generator in eval mode, saved as the reference's 7 x 7 grid ``predictions_<n>.png`` (every image
+        scaled to [0, 1] by its own range, misc.normalize_0_1_batch); the generator goes back to training mode.  The draws follow the
+        reference's order: np.random.choice over range(len(validation loader)), then one torch.randn per (image, stage)."""
         if self.validation_dataset_fid is None or self.path_save_plots is None:
             return
         from .data import image_label_list_of_masks_collate_function
         import numpy as np
+        self.generator.to(device)
+        self.vgg16.to(device)
         self.generator.eval()
         try:
-            idx = np.random.choice(range(len(self.validation_dataset_fid.dataset)), replace=False, size=7)
+            idx = np.random.choice(range(len(self.validation_dataset_fid)), replace=False, size=7)
             images, labels, _ = image_label_list_of_masks_collate_function([self.validation_dataset_fid.dataset[i] for i in idx])
-            fakes = []
+            masks_levels = [misc.get_masks_for_inference(stage, add_batch_size=True, device=device) for stage in range(7)]
+            fakes = torch.empty((7 ** 2,) + tuple(images.shape[1:]), dtype=torch.float32, device=device)
+            counter = 0
             for image, label in zip(images, labels):
                 image, label = image.detach().to(device)[None], label.to(device)[None]
-                feats = self.vgg16(image)
-                for stage in range(7):
-                    masks = misc.get_masks_for_inference(stage, add_batch_size=True, device=device)
+                feats = self.vgg16(image)                      # (frozen, eval mode: the reference recomputes the same pyramid per stage)
+                for masks in masks_levels:
                     z = torch.randn(1, self.latent_dimensions, dtype=torch.float32, device=device)
-                    fakes.append(self.generator(input=z, features=feats, masks=masks, class_id=label.float()).float().cpu())
+                    fakes[counter] = self.generator(input=z, features=feats, masks=masks, class_id=label.float()).float()[0]
+                    counter += 1
             n = getattr(self, "progress_bar", None)
-            torch.save(torch.cat(fakes), os.path.join(self.path_save_plots, 'predictions_{}.pt'.format(n.n if n is not None else 0)))
+            misc.save_image_grid(misc.normalize_0_1_batch(fakes), os.path.join(self.path_save_plots, 'predictions_{}.png'.format(n.n if n is not None else 0)),
+                                 nrow=7)
         finally:
             self.generator.train()

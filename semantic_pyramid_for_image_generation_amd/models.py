@@ -57,8 +57,8 @@ class SNConv2d(nn.Module, _SpectralNormMixin):
         return "%d, %d, kernel_size=%d, spectral_norm" % (self.in_channels, self.out_channels, self.kernel_size)
 
     def forward(self, x, act: int = ACT_NONE, res1=None, res2=None, premasked: bool = False, mask_input: bool = False,
-                pool2: bool = False):
-        return ops.sn_conv2d(x, self, self.kernel_size, act, res1, res2, premasked, mask_input, pool2)
+                pool2: bool = False, dest=None):
+        return ops.sn_conv2d(x, self, self.kernel_size, act, res1, res2, premasked, mask_input, pool2, dest)
 
     def pool2_ok(self, x) -> bool:
         """True if the 2x2 average pooling behind this convolution can ride in its epilogue (ops.conv_pool2_ok)."""
@@ -165,6 +165,82 @@ def _non_sn_params(root: nn.Module):
 _COUNTERS_TICKED = [False]
 
 
+class _Duo:
+    """A tensor of a two-group generator pass (Generator.forward_pair): `all` = both groups' images [g | d] as plain memory (what the
+    launches over 2n images read and write, no autograd), `g` = the first group's images as a tensor of the autograd graph (an alias
+    of the first half of `all`)."""
+    __slots__ = ("all", "g")
+
+    def __init__(self, all_, g):
+        self.all, self.g = all_, g
+
+
+class _GeneratorPair:
+    """The two generator forwards of one training iteration (model_wrapper.py:144-151 without gradient - group d; :165-172 with -
+    group g) as ONE pass over [g | d]: every convolution, resampling and attention launch of the stages below 256 x 256 runs once over
+    2n images (at batch 20 these launches have 80 - 640 work items for 256 CUs), what is per forward - the BatchNorm statistics and
+    their running averages (d first: the reference runs that forward first), the linear trunk, the 256 x 256 final block - runs per
+    group.  The two forwards see the same weight_orig and differ in sigma (every forward advances the power iteration): launches use
+    forward g's packing W / sigma_g with the per-group accumulator scales {1, sigma_g / sigma_d} (ops.conv_two_groups).  Group g's
+    autograd graph is the one a forward of its own would have built: every operator's node is created around its slice of the joint
+    result (ops.Dest), so the backward pass is untouched."""
+
+    def __init__(self, bank, call_d, call_g, handles_g, scales, n: int):
+        self.bank, self.call_d, self.call_g, self.handles_g, self.scales, self.n = bank, call_d, call_g, handles_g, scales, n
+
+    def as_d(self):
+        self.bank.use_call(self.call_d, None)
+
+    def as_g(self):
+        self.bank.use_call(self.call_g, self.handles_g)
+
+    def per_group(self, fn, x: _Duo, shape=None) -> _Duo:
+        """fn(tensor, dest) -> tensor, applied to group d without autograd (first: forward #1 of the iteration) and to group g with; both
+        write their half of one buffer."""
+        n = self.n
+        a = x.all
+        shape = shape if shape is not None else (a.shape[1], a.shape[2], a.shape[3])
+        out = ops.nhwc_empty(2 * n, shape[0], shape[1], shape[2], a.dtype, a.device)
+        self.as_d()
+        with torch.no_grad():
+            fn(a[n:], ops.Dest(out[n:]))
+        self.as_g()
+        g = fn(x.g, ops.Dest(out[:n]))
+        return _Duo(out, g)
+
+    def conv(self, module, x: _Duo, act: int = ACT_NONE, res1: Optional[_Duo] = None, res2: Optional[_Duo] = None) -> _Duo:
+        n = self.n
+        pl = self.call_g.layers[module._sn_slot]
+        y = ops.conv_two_groups(x.all, module, pl, self.scales.data_ptr() + 8 * pl.slot, n, act,
+                                res1.all if res1 is not None else None, res2.all if res2 is not None else None)
+        self.as_g()
+        g = module(x.g, act, res1.g if res1 is not None else None, res2.g if res2 is not None else None, dest=ops.Dest(y[:n], True))
+        return _Duo(y, g)
+
+    def upsample2(self, x: _Duo) -> _Duo:
+        n, a = self.n, x.all
+        y = ops.nhwc_empty(2 * n, a.shape[1], 2 * a.shape[2], 2 * a.shape[3], a.dtype, a.device)
+        ops.L.call("sp_upsample2_fwd", ops.ptr(a), ops.ptr(y), 2 * n, a.shape[2], a.shape[3], a.shape[1], ops.sp_dtype(a.dtype), ops.stream())
+        return _Duo(y, ops.upsample2(x.g, ops.Dest(y[:n], True)))
+
+    def maxpool2(self, x: _Duo) -> _Duo:
+        n, a = self.n, x.all
+        y = ops.nhwc_empty(2 * n, a.shape[1], a.shape[2] // 2, a.shape[3] // 2, a.dtype, a.device)
+        ops.L.call("sp_maxpool2_fwd", ops.ptr(a), ops.ptr(y), 2 * n, a.shape[2], a.shape[3], a.shape[1], 0, ops.sp_dtype(a.dtype), ops.stream())
+        return _Duo(y, ops.maxpool2(x.g, ops.Dest(y[:n], True)))
+
+    def attention(self, q: _Duo, k: _Duo, v: _Duo) -> _Duo:
+        n = self.n
+        o, lse = ops.attention_raw(q.all, k.all, v.all)
+        return _Duo(o, ops.attention_core(q.g, k.g, v.g, ops.Dest(o[:n], True, lse[:n])))
+
+    def scale_add(self, a: _Duo, b: _Duo, gamma) -> _Duo:
+        n = self.n
+        y = torch.empty_like(a.all)
+        ops.L.call("sp_scale_add", ops.ptr(a.all), ops.ptr(b.all), ops.ptr(gamma), ops.ptr(y), a.all.numel(), ops.sp_dtype(y.dtype), ops.stream())
+        return _Duo(y, ops.scale_add(a.g, b.g, gamma, ops.Dest(y[:n], True)))
+
+
 class ConditionalBatchNorm(nn.Module):
     """models.py:469-506."""
 
@@ -175,12 +251,12 @@ class ConditionalBatchNorm(nn.Module):
         self.embedding.weight.data[:, :num_features].fill_(1.0)
         self.embedding.weight.data[:, num_features:].zero_()
 
-    def forward(self, input: torch.Tensor, class_id: torch.Tensor, act: int = ACT_NONE, upsample: bool = False) -> torch.Tensor:
+    def forward(self, input: torch.Tensor, class_id: torch.Tensor, act: int = ACT_NONE, upsample: bool = False, dest=None) -> torch.Tensor:
         bn = self.batch_norm
         if self.training and not _COUNTERS_TICKED[0]:
             bn.num_batches_tracked.add_(1)
         return ops.batch_norm(input, None, None, self.embedding.weight, _class_index(class_id), bn.running_mean, bn.running_var,
-                              bn.momentum, bn.eps, self.training, act, upsample)
+                              bn.momentum, bn.eps, self.training, act, upsample, dest)
 
 
 class SelfAttention(nn.Module):
@@ -203,6 +279,15 @@ class SelfAttention(nn.Module):
         o = ops.attention_core(q, k, v)
         o = self.attention_convolution(o)
         return ops.scale_add(o, input, self.gamma)
+
+    def forward_pair(self, x: _Duo, pp: _GeneratorPair) -> _Duo:
+        """forward() over the two groups of a generator pair pass (every launch over 2n images)."""
+        pooled = pp.maxpool2(x)
+        q = pp.conv(self.query_convolution, x)
+        k = pp.conv(self.key_convolution, pooled)
+        v = pp.conv(self.value_convolution, pooled)
+        o = pp.conv(self.attention_convolution, pp.attention(q, k, v))
+        return pp.scale_add(o, x, self.gamma)
 
 
 class GeneratorResidualBlock(nn.Module):
@@ -237,6 +322,18 @@ class GeneratorResidualBlock(nn.Module):
             r = self.residual_mapping[1](ops.upsample2(input))
         f = mapped() if mapped is not None else self.masked_feature_mapping(masked_features)
         return self.main_block[6](h, ACT_NONE, r, f)                  # (main + residual) + features in the epilogue
+
+    def forward_pair(self, x: _Duo, f: _Duo, cls: torch.Tensor, pp: _GeneratorPair) -> _Duo:
+        """forward() over the two groups of a generator pair pass: the conditional BatchNorms per group (their statistics belong to one
+        forward), everything else once over 2n images.  f: this block's masked-feature mapping of both groups."""
+        h = pp.per_group(lambda t, dest: self.main_block[0](t, cls, ACT_LRELU, dest=dest), x)
+        h = pp.conv(self.main_block[3], pp.upsample2(h))
+        h = pp.per_group(lambda t, dest: self.main_block[4](t, cls, ACT_LRELU, dest=dest), h)
+        if _COMMUTE_1X1:
+            r = pp.upsample2(pp.conv(self.residual_mapping[1], x))
+        else:
+            r = pp.conv(self.residual_mapping[1], pp.upsample2(x))
+        return pp.conv(self.main_block[6], h, ACT_NONE, r, f)
 
 
 class LinearBlock(nn.Module):
@@ -454,29 +551,121 @@ class Generator(nn.Module):
                 else:
                     x = layer(x, None if depth in mapped else ops.mask_concat(features[depth], masks[depth]), cls, mapped.get(depth))
                     depth -= 1
-            fb = self.final_block
-            bn = fb[1]
-            if _FUSE_UPSAMPLE_BN:
-                # UpsamplingBilinear2d -> BatchNorm2d -> LeakyReLU on the expansion of x without writing it (sp_bn_*_up2)
-                x = ops.batch_norm(x, bn.weight, bn.bias, None, None, bn.running_mean, bn.running_var, bn.momentum, bn.eps, self.training,
-                                   ACT_LRELU, "before")
-            else:
-                x = ops.batch_norm(ops.upsample2(x), bn.weight, bn.bias, None, None, bn.running_mean, bn.running_var, bn.momentum,
-                                   bn.eps, self.training, ACT_LRELU)
-            if ops.conv_tail_ok(x, fb[3], fb[5]):
-                try:
-                    return ops.sn_conv2d_tail(x, fb[3], ACT_LRELU, fb[5], ACT_TANH)  # no-grad pass: the 1x1 + tanh ride in the 3x3's epilogue
-                except ops.L.SempyrError:
-                    # the library's own admission test is stricter than conv_tail_ok (its A/B tuning keys, operands of 1 GiB or more -
-                    # a no-grad batch of 128 images): the two layers then run one after the other, as below (round-4 ADVICE)
-                    pass
-            # (the LeakyReLU between the two convolutions: its backward rides in the 1x1's input-gradient epilogue - the separate pass
-            # read and wrote the 64-channel 256 x 256 gradient once more: 84 us per step)
-            x = fb[3](x, ACT_LRELU, premasked=_FUSE_LRELU_BWD)
-            return fb[5](x, ACT_TANH, mask_input=_FUSE_LRELU_BWD)
+            return self._final_block(x)
         finally:
             _COUNTERS_TICKED[0] = ticked_before
             self._bank.end()
+
+    def _final_block(self, x: torch.Tensor) -> torch.Tensor:
+        """models.py:51-61 on the 128 x 128 tensor of one forward."""
+        fb = self.final_block
+        bn = fb[1]
+        if _FUSE_UPSAMPLE_BN:
+            # UpsamplingBilinear2d -> BatchNorm2d -> LeakyReLU on the expansion of x without writing it (sp_bn_*_up2)
+            x = ops.batch_norm(x, bn.weight, bn.bias, None, None, bn.running_mean, bn.running_var, bn.momentum, bn.eps, self.training,
+                               ACT_LRELU, "before")
+        else:
+            x = ops.batch_norm(ops.upsample2(x), bn.weight, bn.bias, None, None, bn.running_mean, bn.running_var, bn.momentum,
+                               bn.eps, self.training, ACT_LRELU)
+        if ops.conv_tail_ok(x, fb[3], fb[5]):
+            try:
+                return ops.sn_conv2d_tail(x, fb[3], ACT_LRELU, fb[5], ACT_TANH)  # no-grad pass: the 1x1 + tanh ride in the 3x3's epilogue
+            except ops.L.SempyrError:
+                # the library's own admission test is stricter than conv_tail_ok (its A/B tuning keys, operands of 1 GiB or more -
+                # a no-grad batch of 128 images): the two layers then run one after the other, as below (round-4 ADVICE)
+                pass
+        # (the LeakyReLU between the two convolutions: its backward rides in the 1x1's input-gradient epilogue - the separate pass
+        # read and wrote the 64-channel 256 x 256 gradient once more: 84 us per step)
+        x = fb[3](x, ACT_LRELU, premasked=_FUSE_LRELU_BWD)
+        return fb[5](x, ACT_TANH, mask_input=_FUSE_LRELU_BWD)
+
+    def forward_pair(self, input_g: torch.Tensor, input_d: torch.Tensor, features: List[torch.Tensor], masks: List[torch.Tensor],
+                     class_id: torch.Tensor):
+        """``(self(input_g, ...), [no_grad] self(input_d, ...))`` where the reference calls self(input_d) FIRST (the discriminator step's
+        fake images, model_wrapper.py:144-151) and self(input_g) second (the generator step, :165-172): both forwards of one training
+        iteration in one pass (_GeneratorPair).  Returns (images of group g with their autograd graph, images of group d without).
+        Spectral-norm u / v advance twice, the BatchNorm running statistics take forward d's batch first, then forward g's, and
+        num_batches_tracked counts both - as two calls would leave them.  Training mode, 16-bit or fp32 storage."""
+        dt = ops.compute_dtype()
+        ops.require_gpu(input_g)
+        if not self.training or input_g.shape != input_d.shape:
+            raise ops.L.SempyrError("Generator.forward_pair: training mode and two latent batches of one shape")
+        n = input_g.shape[0]
+        bank = self._bank
+        dev = input_g.device
+        with torch.no_grad():
+            call_d = bank.begin(True, dt, dev)                 # forward #1: its own power iteration, no autograd handles
+        call_g = bank.begin(True, dt, dev)                     # forward #2
+        handles_g = bank.handles
+        scales = torch.empty(2 * len(bank.specs), dtype=torch.float32, device=dev)
+        # per layer {1, sigma_g / sigma_d}: the launches use g's packing, group d's accumulators are rescaled to its own sigma
+        ops.L.call("sp_sn_pair_scales", ops.ptr(bank.table_dev), len(bank.specs), ops.ptr(call_g.scratch), ops.ptr(call_d.scratch), ops.ptr(scales),
+                   ops.stream())
+        pp = _GeneratorPair(bank, call_d, call_g, handles_g, scales, n)
+        ticked_before = _COUNTERS_TICKED[0]
+        try:
+            self._tick_batch_counters()
+            self._tick_batch_counters()
+            _COUNTERS_TICKED[0] = True
+            self.map_mode, self._map_stash = None, None
+            cls = _class_index(class_id)
+            # the seven masked-feature mappings (models.py:78-94): group d's from the layer (sigma_d), group g's derived from them
+            # (ops.reused_layer: only sigma differs; its weight gradients come from the shared masked input)
+            maps = {}
+            depth = len(features) - 1
+            blocks = [(self.linear_block_1, True), (self.linear_block_2, True)] + [(m, False) for m in self.main_path
+                                                                                   if isinstance(m, GeneratorResidualBlock)]
+            for block, is_linear in blocks:
+                layer = block.masked_feature_mapping
+                src = ops.mask_mul_2d(features[depth], masks[depth]) if is_linear else ops.mask_concat(features[depth], masks[depth])
+                pp.as_d()
+                with torch.no_grad():
+                    if is_linear:
+                        f_d = layer(src)
+                        both = None
+                    else:
+                        both = ops.nhwc_empty(2 * n, layer.out_channels, src.shape[2], src.shape[3], dt, dev)
+                        f_d = layer(src, dest=ops.Dest(both[n:]))
+                    pl_d = ops.packed_layer(layer, True, dt, dev)
+                pp.as_g()
+                f_g = ops.reused_layer(layer, src, f_d, pl_d, None if is_linear else ops.Dest(both[:n]))
+                maps[depth] = (f_d, f_g) if is_linear else _Duo(both, f_g)
+                depth -= 1
+            depth = len(features) - 1
+            # the linear trunk per group (its launches stream weights; batch rows cost nothing there)
+            rows = []
+            for z, first, grad in ((input_d, True, False), (input_g, False, True)):
+                (pp.as_g if grad else pp.as_d)()
+                with torch.set_grad_enabled(grad):
+                    pick = (lambda t: t[1]) if grad else (lambda t: t[0])
+                    x = self.linear_layer(ops.as_rows(z.detach(), dt), ACT_LRELU)
+                    x = self.linear_block_1(x, None, ACT_LRELU, True, (lambda d=depth: pick(maps[d])))
+                    x = self.linear_block_2(x, None, ACT_LRELU, True, (lambda d=depth - 1: pick(maps[d])))
+                    rows.append(x)
+            depth -= 2
+            c4 = rows[0].shape[1] // 16
+            x_all = ops.nhwc_empty(2 * n, c4, 4, 4, dt, dev)
+            with torch.no_grad():
+                ops.rows_to_nhwc(rows[0], c4, 4, 4, ops.Dest(x_all[n:]))
+            x = _Duo(x_all, ops.rows_to_nhwc(rows[1], c4, 4, 4, ops.Dest(x_all[:n])))
+            x = pp.conv(self.convolution_layer[1], x)
+            for layer in self.main_path:
+                if isinstance(layer, SelfAttention):
+                    x = layer.forward_pair(x, pp)
+                else:
+                    x = layer.forward_pair(x, maps[depth], cls, pp)
+                    depth -= 1
+            # the 256 x 256 final block per group: whole rounds of work items at either batch size, and group d (no autograd) takes its
+            # 1x1 + tanh in the 3x3's epilogue
+            pp.as_d()
+            with torch.no_grad():
+                fake_d = self._final_block(x.all[n:])
+            pp.as_g()
+            fake_g = self._final_block(x.g)
+            return fake_g, fake_d
+        finally:
+            _COUNTERS_TICKED[0] = ticked_before
+            bank.end()
 
 
 # --------------------------------------------------------------------------------------------------

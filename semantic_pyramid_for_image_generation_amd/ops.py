@@ -845,13 +845,30 @@ class PairPass:
         return self.scales.data_ptr() + 8 * slot
 
 
+class Dest:
+    """Where an operator's forward leaves its output, handed over OUTSIDE autograd's view of the arguments: `t` is a dense slice of a
+    larger buffer (one group's images of a two-group batch, models.Generator.forward_pair).  filled = False: the operator's launch
+    writes into it; filled = True: a launch over the whole buffer has already produced it and the operator only builds its autograd
+    node around it.  The Function returns a fresh alias of the memory (t.detach()), so autograd never sees the buffer itself."""
+    __slots__ = ("t", "filled", "extra")
+
+    def __init__(self, t: torch.Tensor, filled: bool = False, extra=None):
+        self.t, self.filled, self.extra = t, filled, extra
+
+
+def _dest_tensor(dest: Optional["Dest"], shape, like: torch.Tensor) -> torch.Tensor:
+    if tuple(dest.t.shape) != tuple(shape) or dest.t.dtype != like.dtype or not (is_nhwc(dest.t) if dest.t.dim() == 4 else dest.t.is_contiguous()):
+        raise L.SempyrError("destination slice %s %s does not fit the output %s %s" % (tuple(dest.t.shape), dest.t.dtype, tuple(shape), like.dtype))
+    return dest.t.detach()
+
+
 class _ConvFn(torch.autograd.Function):
     """`handle` is the layer's output of _SNBankFn: it stands for weight_orig in the autograd graph.  pair (a PairPass) with
     handle_b = the same layer's handle of the second forward: a two-group batch."""
 
     @staticmethod
     def forward(ctx, x, handle, bias, res1, res2, pl: PackedLayer, ksize: int, act: int, cout: int, premasked: bool = False,
-                mask_input: bool = False, pool2: bool = False, handle_b=None, pair: Optional[PairPass] = None):
+                mask_input: bool = False, pool2: bool = False, handle_b=None, pair: Optional[PairPass] = None, dest: Optional[Dest] = None):
         require_gpu(x)
         ctx.premasked, ctx.mask_input, ctx.pool2 = premasked, mask_input, pool2
         ctx.pair = pair
@@ -862,9 +879,13 @@ class _ConvFn(torch.autograd.Function):
         if pool2 and (premasked or not conv_pool2_ok(h, w, cout, ksize)):
             raise L.SempyrError("pool2 epilogue is not available for this layer (see conv_pool2_ok)")
         # pool2: y (and res1 / res2) live at the pooled resolution - avgpool2(conv) + bias + residuals, one launch
-        y = nhwc_empty(n, cout, h // 2, w // 2, x.dtype, x.device) if pool2 else nhwc_empty(n, cout, h, w, x.dtype, x.device)
-        conv_launch(x, pl.fwd, bias, y, res1, res2, None, 0.0, n, h, w, cin_p, cout, cout, ksize, act, x.dtype, pool2,
-                    img_scale=img_scale, img_split=img_split, k_real=pl.cin)
+        if dest is not None:
+            y = _dest_tensor(dest, (n, cout, h // 2, w // 2) if pool2 else (n, cout, h, w), x)
+        else:
+            y = nhwc_empty(n, cout, h // 2, w // 2, x.dtype, x.device) if pool2 else nhwc_empty(n, cout, h, w, x.dtype, x.device)
+        if dest is None or not dest.filled:
+            conv_launch(x, pl.fwd, bias, y, res1, res2, None, 0.0, n, h, w, cin_p, cout, cout, ksize, act, x.dtype, pool2,
+                        img_scale=img_scale, img_split=img_split, k_real=pl.cin)
         ctx.pl, ctx.ksize, ctx.act, ctx.cout = pl, ksize, act, cout
         ctx.has_res = (res1 is not None, res2 is not None)
         ctx.save_for_backward(x, y if act != ACT_NONE else None)
@@ -963,7 +984,7 @@ class _ConvFn(torch.autograd.Function):
             if dres is None:
                 raise L.SempyrError("residual gradient with padded channels is not supported")
         return (dx, dh, db, dres if ctx.has_res[0] and need[3] else None, dres if ctx.has_res[1] and need[4] else None,
-                None, None, None, None, None, None, None, dhb, None)
+                None, None, None, None, None, None, None, dhb, None, None)
 
 
 def bias_needed(need, idx) -> bool:
@@ -971,7 +992,7 @@ def bias_needed(need, idx) -> bool:
 
 
 def sn_conv2d(x, module, ksize: int, act: int = ACT_NONE, res1=None, res2=None, premasked: bool = False, mask_input: bool = False,
-              pool2: bool = False):
+              pool2: bool = False, dest: Optional[Dest] = None):
     """Spectral-normalised conv (weight_orig/sigma) + bias (+res1 +res2) -> act, one fused launch.
     premasked / mask_input fuse the LeakyReLU backward of a conv -> LeakyReLU -> conv pair into the second conv's
     input-gradient epilogue: the producer (act = LReLU, premasked=True) skips its own act'(y) pass because its ONLY
@@ -984,9 +1005,25 @@ def sn_conv2d(x, module, ksize: int, act: int = ACT_NONE, res1=None, res2=None, 
     if pair is not None:
         hb = pair.handles_b[pl.slot] if pair.handles_b is not None else None
         return _ConvFn.apply(x, pl.handle, module.bias, res1, res2, pl, ksize, act, module.weight_orig.shape[0], premasked, mask_input,
-                             pool2, hb, pair)
+                             pool2, hb, pair, dest)
     return _ConvFn.apply(x, pl.handle, module.bias, res1, res2, pl, ksize, act, module.weight_orig.shape[0], premasked, mask_input,
-                         pool2)
+                         pool2, None, None, dest)
+
+
+def conv_two_groups(x_all: torch.Tensor, module, pl: PackedLayer, scale_ptr: int, split: int, act: int = ACT_NONE, res1=None, res2=None) -> torch.Tensor:
+    """The forward launch of a spectral-normalised convolution over a batch of TWO groups that belong to two forwards of the network
+    (other sigma: per-group accumulator scales, sp_conv_params.img_scale), WITHOUT autograd: models.Generator.forward_pair builds the
+    first group's autograd node around its slice of the result (sn_conv2d(..., dest=Dest(y[:split], filled=True)))."""
+    with torch.no_grad():
+        require_gpu(x_all)
+        n, h, w, cin_p = dims(x_all)
+        if cin_p != pl.cin_p:
+            raise L.SempyrError("conv input has %d channels, packed weights expect %d" % (cin_p, pl.cin_p))
+        cout, ksize = module.weight_orig.shape[0], module.kernel_size
+        y = nhwc_empty(n, cout, h, w, x_all.dtype, x_all.device)
+        conv_launch(x_all, pl.fwd, module.bias, y, res1, res2, None, 0.0, n, h, w, cin_p, cout, cout, ksize, act, x_all.dtype,
+                    img_scale=scale_ptr, img_split=split, k_real=pl.cin)
+    return y
 
 
 def conv_tail_ok(x: torch.Tensor, m3, m1) -> bool:
@@ -1027,11 +1064,11 @@ class _ReusedLayerFn(torch.autograd.Function):
     the layer's own - weight and bias gradients from the saved input into the current forward's arena; the input needs none."""
 
     @staticmethod
-    def forward(ctx, handle, bias, x_saved, y_prev, pl_prev: PackedLayer, pl: PackedLayer, ksize: int, cout: int):
+    def forward(ctx, handle, bias, x_saved, y_prev, pl_prev: PackedLayer, pl: PackedLayer, ksize: int, cout: int, dest: Optional[Dest] = None):
         require_gpu(y_prev)
         sig_prev = ctypes.c_void_p(pl_prev.scratch + 4 * (pl_prev.cols + 2 * pl_prev.rows))
         sig_now = ctypes.c_void_p(pl.scratch + 4 * (pl.cols + 2 * pl.rows))
-        y = torch.empty_like(y_prev)
+        y = _dest_tensor(dest, y_prev.shape, y_prev) if dest is not None else torch.empty_like(y_prev)
         if y_prev.dim() == 4:
             n, h, w, c = dims(y_prev)
             rows, ld = n * h * w, c
@@ -1051,7 +1088,7 @@ class _ReusedLayerFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         dt = x.dtype
         if not need[0]:
-            return (None,) * 8
+            return (None,) * 9
         dwsn = pl.call.dw_slot(pl)
         db = pl.call.db_slot(pl) if need[1] else None
         if x.dim() == 4:
@@ -1077,15 +1114,15 @@ class _ReusedLayerFn(torch.autograd.Function):
                 db = torch.empty(pl.rows, dtype=torch.float32, device=x.device)
             L.call("sp_linear_wgrad", ptr(x), x.stride(0), ptr(dy), dy.stride(0), ptr(dwsn), pl.cin_p, ptr(db), b, k, pl.rows, sp_dtype(dt), stream())
         direct = pl.call.bank.direct_grads
-        return _zero1(x.device), (None if (direct or not need[1]) else db), None, None, None, None, None, None
+        return _zero1(x.device), (None if (direct or not need[1]) else db), None, None, None, None, None, None, None
 
 
-def reused_layer(module, x_saved, y_prev, pl_prev: PackedLayer):
+def reused_layer(module, x_saved, y_prev, pl_prev: PackedLayer, dest: Optional[Dest] = None):
     """`module` applied to `x_saved` in the forward in flight, computed from its output `y_prev` of the earlier forward whose
     PackedLayer is pl_prev (see _ReusedLayerFn)."""
     pl = packed_layer(module, module.training, y_prev.dtype, y_prev.device)
     ksize = getattr(module, "kernel_size", 1)
-    return _ReusedLayerFn.apply(pl.handle, module.bias, x_saved, y_prev, pl_prev, pl, ksize, module.weight_orig.shape[0])
+    return _ReusedLayerFn.apply(pl.handle, module.bias, x_saved, y_prev, pl_prev, pl, ksize, module.weight_orig.shape[0], dest)
 
 
 def linear_launch(x, w_ptr: int, kp: int, bias, res, y, b: int, k: int, n: int, act: int) -> None:
@@ -1156,7 +1193,7 @@ class _BatchNormFn(torch.autograd.Function):
     """x -> act(scale * xhat + bias); (scale,bias) from (gamma,beta) or from emb[cls] (conditional)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, emb, cls, running_mean, running_var, momentum, eps, training, act, upsample=False):
+    def forward(ctx, x, gamma, beta, emb, cls, running_mean, running_var, momentum, eps, training, act, upsample=False, dest: Optional[Dest] = None):
         """upsample: False; True = CBN -> act -> bilinear x2 in one pass (sp_bn_apply_upsample2); "before" = the normalised tensor
         is the bilinear x2 expansion of x, never materialised (sp_bn_*_up2: the generator's final block)."""
         require_gpu(x)
@@ -1186,7 +1223,7 @@ class _BatchNormFn(torch.autograd.Function):
             L.call("sp_bn_apply_upsample2", ptr(x), ptr(y), n, h, w, c, ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(emb),
                    ptr(cls), act, sp_dtype(x.dtype), stream())
         else:
-            y = nhwc_empty(n, c, h, w, x.dtype, dev)
+            y = _dest_tensor(dest, (n, c, h, w), x) if dest is not None else nhwc_empty(n, c, h, w, x.dtype, dev)
             L.call("sp_bn_apply", ptr(x), ptr(y), n, h * w, c, ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(emb), ptr(cls), act,
                    sp_dtype(x.dtype), stream())
         ctx.act, ctx.training, ctx.upsample = act, training, upsample
@@ -1217,7 +1254,7 @@ class _BatchNormFn(torch.autograd.Function):
                    ptr(cls), ctx.act, ptr(red), ptr(ctmp), ptr(dgamma), ptr(dbeta), ptr(demb), classes, sp_dtype(dt), stream())
             dx = nhwc_empty(n, c, h, w, dt, dev)
             L.call("sp_upsample2_bwd", ptr(du), ptr(dx), n, h, w, c, sp_dtype(dt), stream())
-            return dx, dgamma, dbeta, demb, None, None, None, None, None, None, None, None
+            return dx, dgamma, dbeta, demb, None, None, None, None, None, None, None, None, None
         if ctx.upsample:
             dlow = nhwc_empty(n, c, h, w, dt, dev)
             L.call("sp_upsample2_bwd", ptr(dy), ptr(dlow), n, h, w, c, sp_dtype(dt), stream())
@@ -1235,11 +1272,13 @@ class _BatchNormFn(torch.autograd.Function):
             dbeta = torch.empty(c, dtype=torch.float32, device=dev)
         L.call("sp_bn_backward", ptr(dy), ptr(x), ptr(dx), n, h * w, c, ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(emb),
                ptr(cls), ctx.act, ptr(red), ptr(ctmp), ptr(dgamma), ptr(dbeta), ptr(demb), classes, sp_dtype(dt), stream())
-        return dx, dgamma, dbeta, demb, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, demb, None, None, None, None, None, None, None, None, None
 
 
-def batch_norm(x, gamma, beta, emb, cls, running_mean, running_var, momentum, eps, training, act, upsample=False):
-    return _BatchNormFn.apply(x, gamma, beta, emb, cls, running_mean, running_var, momentum, eps, training, act, upsample)
+def batch_norm(x, gamma, beta, emb, cls, running_mean, running_var, momentum, eps, training, act, upsample=False, dest: Optional[Dest] = None):
+    if dest is not None and upsample:
+        raise L.SempyrError("batch_norm: a destination slice goes with the plain (not up-sampling) form")
+    return _BatchNormFn.apply(x, gamma, beta, emb, cls, running_mean, running_var, momentum, eps, training, act, upsample, dest)
 
 
 # ======================================================================================================
@@ -1247,11 +1286,12 @@ def batch_norm(x, gamma, beta, emb, cls, running_mean, running_var, momentum, ep
 # ======================================================================================================
 class _Upsample2Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, dest: Optional[Dest] = None):
         require_gpu(x)
         n, h, w, c = dims(x)
-        y = nhwc_empty(n, c, 2 * h, 2 * w, x.dtype, x.device)
-        L.call("sp_upsample2_fwd", ptr(x), ptr(y), n, h, w, c, sp_dtype(x.dtype), stream())
+        y = _dest_tensor(dest, (n, c, 2 * h, 2 * w), x) if dest is not None else nhwc_empty(n, c, 2 * h, 2 * w, x.dtype, x.device)
+        if dest is None or not dest.filled:
+            L.call("sp_upsample2_fwd", ptr(x), ptr(y), n, h, w, c, sp_dtype(x.dtype), stream())
         ctx.shape = (n, h, w, c)
         return y
 
@@ -1261,11 +1301,11 @@ class _Upsample2Fn(torch.autograd.Function):
         dy = as_nhwc(dy)
         dx = nhwc_empty(n, c, h, w, dy.dtype, dy.device)
         L.call("sp_upsample2_bwd", ptr(dy), ptr(dx), n, h, w, c, sp_dtype(dy.dtype), stream())
-        return dx
+        return dx, None
 
 
-def upsample2(x):
-    return _Upsample2Fn.apply(x)
+def upsample2(x, dest: Optional[Dest] = None):
+    return _Upsample2Fn.apply(x, dest)
 
 
 class _AvgPool2Fn(torch.autograd.Function):
@@ -1336,11 +1376,12 @@ def act_avgpool2(x, act: int):
 
 class _MaxPool2Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, dest: Optional[Dest] = None):
         require_gpu(x)
         n, h, w, c = dims(x)
-        y = nhwc_empty(n, c, h // 2, w // 2, x.dtype, x.device)
-        L.call("sp_maxpool2_fwd", ptr(x), ptr(y), n, h, w, c, 0, sp_dtype(x.dtype), stream())
+        y = _dest_tensor(dest, (n, c, h // 2, w // 2), x) if dest is not None else nhwc_empty(n, c, h // 2, w // 2, x.dtype, x.device)
+        if dest is None or not dest.filled:
+            L.call("sp_maxpool2_fwd", ptr(x), ptr(y), n, h, w, c, 0, sp_dtype(x.dtype), stream())
         ctx.save_for_backward(x)
         return y
 
@@ -1351,11 +1392,11 @@ class _MaxPool2Fn(torch.autograd.Function):
         dy = as_nhwc(dy, x.dtype)
         dx = nhwc_empty(n, c, h, w, x.dtype, x.device)
         L.call("sp_maxpool2_bwd", ptr(dy), ptr(x), ptr(dx), n, h, w, c, 0, sp_dtype(x.dtype), stream())
-        return dx
+        return dx, None
 
 
-def maxpool2(x):
-    return _MaxPool2Fn.apply(x)
+def maxpool2(x, dest: Optional[Dest] = None):
+    return _MaxPool2Fn.apply(x, dest)
 
 
 class _AdaptiveAvgFn(torch.autograd.Function):
@@ -1412,10 +1453,11 @@ class _ScaleAddFn(torch.autograd.Function):
     """y = gamma * a + b   (models.py:274)."""
 
     @staticmethod
-    def forward(ctx, a, b, gamma):
+    def forward(ctx, a, b, gamma, dest: Optional[Dest] = None):
         require_gpu(a)
-        y = torch.empty_like(a)
-        L.call("sp_scale_add", ptr(a), ptr(b), ptr(gamma), ptr(y), a.numel(), sp_dtype(a.dtype), stream())
+        y = _dest_tensor(dest, a.shape, a) if dest is not None else torch.empty_like(a)
+        if dest is None or not dest.filled:
+            L.call("sp_scale_add", ptr(a), ptr(b), ptr(gamma), ptr(y), a.numel(), sp_dtype(a.dtype), stream())
         ctx.save_for_backward(a, gamma)
         return y
 
@@ -1427,7 +1469,7 @@ class _ScaleAddFn(torch.autograd.Function):
         dg = torch.empty(1, dtype=torch.float32, device=a.device)
         part = torch.empty(512, dtype=torch.float32, device=a.device)
         L.call("sp_scale_add_bwd", ptr(dy), ptr(a), ptr(gamma), ptr(da), ptr(dg), ptr(part), a.numel(), sp_dtype(a.dtype), stream())
-        return da, dy, dg
+        return da, dy, dg, None
 
 
 class _SplitRowsFn(torch.autograd.Function):
@@ -1466,18 +1508,20 @@ def split_rows(x, split: int):
     return _SplitRowsFn.apply(x, split)
 
 
-def scale_add(a, b, gamma):
-    return _ScaleAddFn.apply(a, b, gamma)
+def scale_add(a, b, gamma, dest: Optional[Dest] = None):
+    return _ScaleAddFn.apply(a, b, gamma, dest)
 
 
 class _PermuteFn(torch.autograd.Function):
     """(B, C*HW) in NCHW-flatten order -> NHWC tensor (B, C, H, W) (models.py:83), or back."""
 
     @staticmethod
-    def forward(ctx, x, c, h, w, to_nhwc):
+    def forward(ctx, x, c, h, w, to_nhwc, dest: Optional[Dest] = None):
         require_gpu(x)
         b = x.shape[0]
-        if to_nhwc:
+        if to_nhwc and dest is not None:
+            y = _dest_tensor(dest, (b, c, h, w), x)
+        elif to_nhwc:
             y = nhwc_empty(b, c, h, w, x.dtype, x.device)
         else:
             y = torch.empty((b, c * h * w), dtype=x.dtype, device=x.device)
@@ -1495,11 +1539,11 @@ class _PermuteFn(torch.autograd.Function):
             dy = as_rows(dy)
             dx = nhwc_empty(b, c, h, w, dy.dtype, dy.device)
         L.call("sp_permute_chw_hwc", ptr(dy), ptr(dx), b, c, h * w, 0 if to_nhwc else 1, sp_dtype(dy.dtype), stream())
-        return dx, None, None, None, None
+        return dx, None, None, None, None, None
 
 
-def rows_to_nhwc(x, c, h, w):
-    return _PermuteFn.apply(x, c, h, w, True)
+def rows_to_nhwc(x, c, h, w, dest: Optional[Dest] = None):
+    return _PermuteFn.apply(x, c, h, w, True, dest)
 
 
 class _IngestFn(torch.autograd.Function):
@@ -1588,14 +1632,20 @@ def mask_mul_2d(feat: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
 # ======================================================================================================
 class _AttentionFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v):
+    def forward(ctx, q, k, v, dest: Optional[Dest] = None):
+        """dest (filled): extra = the log-sum-exp rows of the same images, as the launch over the whole batch left them."""
         require_gpu(q)
         b, hq, wq, d = dims(q)
         _, hk, wk, dv = dims(v)
         n, nk = hq * wq, hk * wk
-        o = nhwc_empty(b, dv, hq, wq, q.dtype, q.device)
-        lse = torch.empty((b, n), dtype=torch.float32, device=q.device)
-        L.call("sp_attention_fwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), b, n, nk, d, dv, sp_dtype(q.dtype), stream())
+        if dest is not None:
+            if not dest.filled or dest.extra is None:
+                raise L.SempyrError("attention_core: a destination must come filled, with its log-sum-exp rows")
+            o, lse = _dest_tensor(dest, (b, dv, hq, wq), q), dest.extra
+        else:
+            o = nhwc_empty(b, dv, hq, wq, q.dtype, q.device)
+            lse = torch.empty((b, n), dtype=torch.float32, device=q.device)
+            L.call("sp_attention_fwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), b, n, nk, d, dv, sp_dtype(q.dtype), stream())
         ctx.save_for_backward(q, k, v, lse)
         return o
 
@@ -1612,7 +1662,7 @@ class _AttentionFn(torch.autograd.Function):
         dv32 = torch.empty(nqb * b * nk * dv, dtype=torch.float32, device=q.device)
         L.call("sp_attention_bwd", ptr(q), ptr(k), ptr(v), ptr(do), ptr(lse), ptr(dq), ptr(dk32), ptr(dv32), ptr(dk), ptr(dvv),
                b, n, nk, d, dv, sp_dtype(q.dtype), stream())
-        return dq, dk, dvv
+        return dq, dk, dvv, None
 
 
 _ATTN_SLABS = {}
@@ -1628,8 +1678,21 @@ def _attention_slabs(n, nk, d, dv, dtype) -> int:
     return v
 
 
-def attention_core(q, k, v):
-    return _AttentionFn.apply(q, k, v)
+def attention_core(q, k, v, dest: Optional[Dest] = None):
+    return _AttentionFn.apply(q, k, v, dest)
+
+
+def attention_raw(q, k, v):
+    """(output, log-sum-exp rows) of the attention core without autograd (a batch of two groups, models.Generator.forward_pair)."""
+    with torch.no_grad():
+        require_gpu(q)
+        b, hq, wq, d = dims(q)
+        _, hk, wk, dv = dims(v)
+        n, nk = hq * wq, hk * wk
+        o = nhwc_empty(b, dv, hq, wq, q.dtype, q.device)
+        lse = torch.empty((b, n), dtype=torch.float32, device=q.device)
+        L.call("sp_attention_fwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), b, n, nk, d, dv, sp_dtype(q.dtype), stream())
+    return o, lse
 
 
 # ======================================================================================================

@@ -70,6 +70,74 @@ def test_pair_pass_equals_two_forwards(cf, batch, dtype, tol_pred, tol_grad):
         assert torch.equal(b0[n], b1[n]), n
 
 
+def _gen(cf, seed):
+    Gsd, _, _ = gu.synth_states({"cf": cf, "seed": seed})
+    G = sp.Generator(channels_factor=cf)
+    G.load_state_dict(Gsd)
+    G = G.cuda().train()
+    G._bank.direct_grads, G._bank.expected_passes = True, 1
+    return G
+
+
+@pytest.mark.parametrize("cf,batch,dtype,tol_img,tol_grad", [(4, 4, torch.float32, 2e-5, 3e-4), (1, 6, torch.float32, 2e-5, 3e-4),
+                                                            (1, 20, torch.bfloat16, 3e-2, 8e-2)])
+def test_generator_pair_pass_equals_two_forwards(cf, batch, dtype, tol_img, tol_grad):
+    """Generator.forward_pair (round 5; the two generator forwards of an iteration, /root/reference/model_wrapper.py:144-151 without
+    gradient and :165-172 with, as one pass over 2B images below 256 x 256) against the two calls the reference makes, in its order:
+    both image batches, every parameter gradient of the second forward, and ALL buffers - spectral-norm u / v after two power
+    iterations, the BatchNorm running statistics after forward d's update then forward g's, num_batches_tracked + 2 - must agree
+    (buffers: u / v and the counters bit for bit; the running statistics to the rounding of the activations they average)."""
+    ops.set_compute_dtype(dtype)
+    g = torch.Generator().manual_seed(17)
+    images, labels, masks = gu.golden_batches(4, 5)[0]
+    reps = (batch + 3) // 4
+    images = images.repeat(reps, 1, 1, 1)[:batch].cuda()
+    labels = labels.repeat(reps, 1)[:batch].cuda()
+    masks = [m.repeat(reps, *([1] * (m.dim() - 1)))[:batch].cuda() for m in masks]
+    z_d, z_g = torch.randn(batch, 128, generator=g).cuda(), torch.randn(batch, 128, generator=g).cuda()
+    seed_img = torch.randn(batch, 3, 256, 256, generator=g).cuda()
+    V = sp.VGG16()
+    _, _, Vsd = gu.synth_states({"cf": cf, "seed": 3})
+    V.load_state_dict(Vsd)
+    V.cuda().eval()
+    with torch.no_grad():
+        feats = V(images)
+    outs = []
+    for mode in ("two", "pair"):
+        G = _gen(cf, 3)
+        if mode == "two":
+            with torch.no_grad():
+                fake_d = G(z_d, feats, masks, labels)
+            fake_g = G(z_g, feats, masks, labels)
+        else:
+            fake_g, fake_d = G.forward_pair(z_g, z_d, feats, masks, labels)
+            assert not fake_d.requires_grad and fake_g.requires_grad
+        fake_g.backward(seed_img.to(fake_g.dtype))
+        G._bank.collect_extra()
+        torch.cuda.synchronize()
+        outs.append((fake_d.detach().float().clone(), fake_g.detach().float().clone(),
+                     {n: p.grad.detach().float().clone() for n, p in G.named_parameters() if p.grad is not None},
+                     {n: b.detach().clone() for n, b in G.named_buffers()}))
+    (d0, g0, gr0, b0), (d1, g1, gr1, b1) = outs
+    for a, b, tag in ((d0, d1, "forward d"), (g0, g1, "forward g")):
+        err = float((a - b).abs().max())
+        assert err <= tol_img, (tag, err)
+    assert set(gr0) == set(gr1) and len(gr0) == len(list(G.parameters()))
+    dens = sorted(float(gr0[n].abs().max()) for n in gr0)
+    floor = 1e-2 * dens[len(dens) // 2]
+    for n in gr0:
+        den = max(float(gr0[n].abs().max()), floor)
+        err = float((gr0[n] - gr1[n]).abs().max()) / den
+        assert err <= tol_grad, (n, err)
+    for n in b0:
+        if n.endswith("weight_u") or n.endswith("weight_v") or n.endswith("num_batches_tracked"):
+            assert torch.equal(b0[n], b1[n]), n
+        else:
+            assert torch.allclose(b0[n].float(), b1[n].float(), rtol=1e-5 if dtype == torch.float32 else 2e-2,
+                                  atol=1e-7 if dtype == torch.float32 else 2e-3), n
+    assert int(b1["final_block.1.num_batches_tracked"]) == 2
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", [
     # (cin, cout, ksize, h, w, pool2, up, act): one per convolution route the discriminator trunk takes

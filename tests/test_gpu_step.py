@@ -4,6 +4,8 @@ reference's own ModelWrapper.train() loop (tests/golden/, see make_golden.py) an
 Tolerances (north_star): <= 1e-3 relative on generator pixels and loss scalars in fp32 mode.  The bf16 mode
 (bf16 storage, bf16 MFMA, fp32 accumulate) is held to 2x its MEASURED error against the same goldens (BF16_MEASURED below:
 losses ~1.3e-3 relative, pixels 3.3e-2 absolute at the worst of 4096 samples, 6.3e-3 rms)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -302,6 +304,58 @@ def test_eval_mode_generator_forward_vs_oracle():
     assert tuple(img.shape) == (1, 3, 256, 256)
     assert float((img.float().cpu() - ref).abs().max()) <= 2e-3
     assert torch.equal(G.linear_layer.weight_u, u_before), "eval mode must not run the power iteration"
+
+
+def test_inference_writes_the_reference_sample_grid(tmp_path):
+    """ModelWrapper.inference() (/root/reference/model_wrapper.py:247-296), executed: 7 validation images x 7 single-stage mask sets,
+    batch 1, eval-mode generator reached through an nn.DataParallel wrapper (the reference's `.module` path), one latent per sample in
+    the reference's order; the PNG it writes is the 7 x 7 grid of the CPU oracle's eval-mode outputs for the same draws (each image
+    scaled by its own range, 8-bit: within one level on all but isolated pixels), and the generator is back in training mode with
+    untouched spectral-norm vectors."""
+    import numpy as np
+    from semantic_pyramid_for_image_generation_amd import misc
+    meta, _ = gu.load("step_cf4_b4_seed1")
+    meta = dict(meta, cf=8)
+    ops.set_compute_dtype(torch.float32)
+    G, D, V = build(meta)
+    Gsd, _, Vsd = gu.synth_states(meta)
+    oG, oV = O.make_state(Gsd), O.make_state(Vsd, frozen=True)
+    samples = []
+    for k in range(3):
+        images, labels, masks = gu.golden_batches(4, 20 + k)[0]
+        samples += [(images[i], labels[i], [m[i] for m in masks]) for i in range(4)]
+
+    class Loader(list):                                       # what inference() touches of a DataLoader: len() and .dataset
+        dataset = samples
+    loader = Loader(range(len(samples)))
+    mw = sp.ModelWrapper(generator=torch.nn.DataParallel(G), discriminator=torch.nn.DataParallel(D), vgg16=V, training_dataset=None,
+                         validation_dataset=loader, save_data_path=str(tmp_path))
+    G.train()
+    u_before = G.linear_layer.weight_u.detach().clone()
+    np.random.seed(5)
+    torch.manual_seed(77)
+    mw.inference(device="cuda")
+    assert G.training and torch.equal(G.linear_layer.weight_u, u_before)
+    path = [os.path.join(mw.path_save_plots, f) for f in os.listdir(mw.path_save_plots)]
+    assert len(path) == 1 and path[0].endswith("predictions_0.png")
+    got = misc.load_png_rgb8(path[0]).astype(np.int32)
+    assert got.shape == (7 * 258 + 2, 7 * 258 + 2, 3)
+    # the same draws again: np.random.choice for the images, the device's generator for the 49 latents
+    np.random.seed(5)
+    torch.manual_seed(77)
+    idx = np.random.choice(range(len(loader)), replace=False, size=7)
+    fakes = []
+    with torch.no_grad():
+        for i in idx:
+            image, label, _ = samples[i]
+            feats = O.vgg16_forward(oV, image[None])
+            for stage in range(7):
+                masks = misc.get_masks_for_inference(stage, add_batch_size=True)
+                z = torch.randn(1, 128, dtype=torch.float32, device="cuda").cpu()
+                fakes.append(O.generator_forward(oG, z, feats, masks, label[None].float(), False)[0])
+    want = misc.image_grid(misc.normalize_0_1_batch(torch.stack(fakes)), nrow=7).mul(255).add(0.5).clamp(0, 255).permute(1, 2, 0).to(torch.uint8).numpy().astype(np.int32)
+    diff = np.abs(got - want)
+    assert diff.max() <= 3 and float((diff > 1).mean()) <= 1e-3, (int(diff.max()), float((diff > 1).mean()))
 
 
 def test_batchnorm_step_counters_batched():

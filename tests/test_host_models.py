@@ -188,3 +188,29 @@ def test_device_mask_seeds_leave_the_global_generator_alone():
     g2 = synthetic._private_generator()                         # same initial seed -> same mask sequence
     assert int(torch.randint(0, (1 << 63) - 1, (1,), dtype=torch.int64, generator=g2)) == draws[0]
     synthetic._PRIVATE_GEN[0] = None
+
+
+def test_image_grid_png_matches_torchvisions_layout(tmp_path):
+    """misc.save_image_grid = torchvision.utils.save_image(x, path, nrow) of /root/reference/model_wrapper.py:290-292 without
+    torchvision: make_grid's geometry (padding 2, zeros) and save_image's rounding, as a PNG any decoder reads (PIL here)."""
+    import numpy as np
+    from semantic_pyramid_for_image_generation_amd import misc
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(10, 3, 12, 9, generator=g)
+    path = str(tmp_path / "grid.png")
+    misc.save_image_grid(x, path, nrow=7)
+    got = misc.load_png_rgb8(path)
+    assert got.shape == (2 * 14 + 2, 7 * 11 + 2, 3)
+    want = np.zeros(got.shape, dtype=np.uint8)
+    for k in range(10):
+        r, c = divmod(k, 7)
+        tile = (x[k] * 255 + 0.5).clamp(0, 255).permute(1, 2, 0).to(torch.uint8).numpy()
+        want[r * 14 + 2:r * 14 + 14, c * 11 + 2:c * 11 + 11] = tile
+    assert (got == want).all()
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    assert (np.asarray(Image.open(path).convert("RGB")) == want).all()
+    n01 = misc.normalize_0_1_batch(torch.randn(3, 3, 4, 4, generator=g))
+    assert float(n01.min()) == 0.0 and float(n01.max()) == 1.0
