@@ -14,6 +14,7 @@ results beyond floating-point summation order.  The kernel library itself reads 
     fuse_bn_upsample      SP_FUSE_BN_UPSAMPLE    0        CBN + LeakyReLU + bilinear x2 in one kernel (measured slower)
     fuse_upsample_bn      SP_FUSE_UPSAMPLE_BN    1        bilinear x2 -> BatchNorm -> LeakyReLU of the generator's final block without materialising the 256 x 256 expansion
     fuse_tail             SP_FUSE_TAIL           1        no-grad generator forward: its last conv1x1 + tanh in the epilogue of the conv3x3 before it
+    fuse_tail_grad        SP_FUSE_TAIL_GRAD      1        the same in the generator forward WITH autograd: one launch stores the 64-channel tensor and the image (round 5)
     pool2_bwd_fused       SP_POOL2_BWD_FUSED     1        pooled gradients read directly by dgrad / weight gradient (no full-resolution tensor)
     graph_after           SP_GRAPH_AFTER         3        ModelWrapper.train(): capture HIP graphs after this many eager iterations (0 = never)
     d_pair                SP_D_PAIR              1        D(real) and D(fake) of the discriminator step as one two-group pass over 2B images (models.Discriminator.forward_pair)
@@ -58,6 +59,7 @@ class Config:
     vgg_pair: bool = True
     vgg_pool_idx: bool = True
     g_pair: bool = True
+    fuse_tail_grad: bool = True
 
     @classmethod
     def from_env(cls) -> "Config":
@@ -69,7 +71,8 @@ class Config:
                    side_features=_flag("SP_SIDE_FEATURES", False),
                    fuse_upsample_bn=_flag("SP_FUSE_UPSAMPLE_BN", True), fuse_tail=_flag("SP_FUSE_TAIL", True),
                    wgrad_side_stream=int(os.environ.get("SP_WGRAD_SIDE_STREAM", "0")), reuse_feature_maps=_flag("SP_REUSE_FEATURE_MAPS", True), vgg_pair=_flag("SP_VGG_PAIR", True),
-                   vgg_pool_idx=_flag("SP_VGG_POOL_IDX", True), g_pair=_flag("SP_G_PAIR", True))
+                   vgg_pool_idx=_flag("SP_VGG_POOL_IDX", True), g_pair=_flag("SP_G_PAIR", True),
+                   fuse_tail_grad=_flag("SP_FUSE_TAIL_GRAD", True))
 
 
 CFG = Config.from_env()

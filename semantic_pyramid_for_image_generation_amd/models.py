@@ -574,6 +574,16 @@ class Generator(nn.Module):
                 # the library's own admission test is stricter than conv_tail_ok (its A/B tuning keys, operands of 1 GiB or more -
                 # a no-grad batch of 128 images): the two layers then run one after the other, as below (round-4 ADVICE)
                 pass
+        if ops.conv_tail_ok(x, fb[3], fb[5], with_grad=True):
+            # the pass WITH autograd (round 5): the same single launch, which here also stores the 64-channel tensor (the 1x1 layer's
+            # weight gradient and the LeakyReLU's derivative read it); the two layers' autograd nodes are built around the results
+            try:
+                mid, img = ops.sn_conv2d_tail(x, fb[3], ACT_LRELU, fb[5], ACT_TANH, keep_mid=True)
+            except ops.L.SempyrError:
+                mid = None
+            if mid is not None:
+                h = fb[3](x, ACT_LRELU, premasked=_FUSE_LRELU_BWD, dest=ops.Dest(mid, True))
+                return fb[5](h, ACT_TANH, mask_input=_FUSE_LRELU_BWD, dest=ops.Dest(img, True))
         # (the LeakyReLU between the two convolutions: its backward rides in the 1x1's input-gradient epilogue - the separate pass
         # read and wrote the 64-channel 256 x 256 gradient once more: 84 us per step)
         x = fb[3](x, ACT_LRELU, premasked=_FUSE_LRELU_BWD)

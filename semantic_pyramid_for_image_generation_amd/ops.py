@@ -1026,25 +1026,33 @@ def conv_two_groups(x_all: torch.Tensor, module, pl: PackedLayer, scale_ptr: int
     return y
 
 
-def conv_tail_ok(x: torch.Tensor, m3, m1) -> bool:
+def conv_tail_ok(x: torch.Tensor, m3, m1, with_grad: bool = False) -> bool:
     """True if conv3x3(m3) -> act -> conv1x1(m1) -> act can run as ONE launch with the 1x1 layer in the 3x3's epilogue
-    (include/sempyr.h: sp_conv_params.tail_w) - a forward pass without autograd only."""
+    (include/sempyr.h: sp_conv_params.tail_w).  with_grad = False: a forward pass without autograd (the 64-channel tensor is never
+    written); True: the pass with autograd, where the launch also stores the 64-channel tensor the backward pass reads
+    (config.CFG.fuse_tail_grad)."""
     n, h, w, c = dims(x)
-    return (not torch.is_grad_enabled() and CFG.fuse_tail and is_16bit(x.dtype) and m3.kernel_size == 3 and m1.kernel_size == 1
+    if with_grad != torch.is_grad_enabled() or (with_grad and not CFG.fuse_tail_grad):
+        return False
+    return (CFG.fuse_tail and is_16bit(x.dtype) and m3.kernel_size == 3 and m1.kernel_size == 1
             and m3.out_channels == 64 and m1.in_channels == 64 and m1.out_channels <= 4 and h % 16 == 0 and w % 32 == 0)
 
 
-def sn_conv2d_tail(x, m3, act3: int, m1, act1: int) -> torch.Tensor:
-    """act1(conv1x1(act3(conv3x3(x)))) of two spectral-normalised layers in one launch (no autograd; conv_tail_ok): the generator's
-    last two layers (models.py:55-61).  The 64-channel intermediate is neither written nor read back."""
+def sn_conv2d_tail(x, m3, act3: int, m1, act1: int, keep_mid: bool = False):
+    """act1(conv1x1(act3(conv3x3(x)))) of two spectral-normalised layers in one launch (no autograd of its own; conv_tail_ok): the
+    generator's last two layers (models.py:55-61).  keep_mid = False: the 64-channel intermediate is neither written nor read back;
+    True: it is stored as well and (intermediate, output) is returned - the caller builds the two layers' autograd nodes around them
+    (Dest(..., filled=True)), so that the pass WITH gradient saves the 1x1 layer's launch and its read of the 168 MB tensor."""
     require_gpu(x)
+    x = x.detach()
     pl3 = packed_layer(m3, m3.training, x.dtype, x.device)
     pl1 = packed_layer(m1, m1.training, x.dtype, x.device)
     n, h, w, cin_p = dims(x)
     cout1 = m1.out_channels
     y = nhwc_empty(n, cout1, h, w, x.dtype, x.device)
+    mid = nhwc_empty(n, 64, h, w, x.dtype, x.device) if keep_mid else None
     p = L.SpConvParams()
-    p.x, p.w, p.bias, p.y = x.data_ptr(), pl3.fwd, (m3.bias.data_ptr() if m3.bias is not None else None), None
+    p.x, p.w, p.bias, p.y = x.data_ptr(), pl3.fwd, (m3.bias.data_ptr() if m3.bias is not None else None), (mid.data_ptr() if keep_mid else None)
     p.n, p.h, p.w_, p.cin_p, p.cout, p.ldy, p.ksize, p.act, p.dtype = n, h, w, cin_p, 64, 64, 3, act3, sp_dtype(x.dtype)
     p.tail_w, p.tail_bias, p.tail_y = pl1.fwd, (m1.bias.data_ptr() if m1.bias is not None else None), y.data_ptr()
     p.tail_cout, p.tail_act, p.tail_ld = cout1, act1, cout1
@@ -1055,7 +1063,7 @@ def sn_conv2d_tail(x, m3, act3: int, m1, act1: int) -> torch.Tensor:
         _probed("fwd", 2.0 * n * h * w * 64 * (9 * pl3.cin + cout1), False, launch, (3, cin_p, 64, h, w, n))
     else:
         launch()
-    return y
+    return (mid, y) if keep_mid else y
 
 
 class _ReusedLayerFn(torch.autograd.Function):

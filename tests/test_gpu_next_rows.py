@@ -10,6 +10,8 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
+from semantic_pyramid_for_image_generation_amd.config import CFG  # noqa: E402
+
 import golden_util as gu  # noqa: E402
 import semantic_pyramid_for_image_generation_amd as sp  # noqa: E402
 from semantic_pyramid_for_image_generation_amd import models, ops, params, synthetic  # noqa: E402
@@ -239,7 +241,7 @@ class _HalvingReducer:
         pass
 
 
-def test_eager_group_hooks_reduce_every_gradient_exactly_once():
+def test_eager_group_hooks_reduce_every_gradient_exactly_once(monkeypatch):
     """Round-3 ADVICE (medium): on the eager data-parallel path the bank's layer groups hand their flat range to the reducer from
     INSIDE the backward pass.  A gradient that reaches the flat buffer only after .backward() returned (the discriminator head's
     classification bias used to) is then skipped as 'already reduced' - un-averaged on N > 1 ranks - and its late copy races with
@@ -249,6 +251,9 @@ def test_eager_group_hooks_reduce_every_gradient_exactly_once():
     images, labels, masks = gu.golden_batches(4, 1)[0]
     images, labels, masks = images.cuda(), labels.cuda(), [m.cuda() for m in masks]
     noise = torch.randn(2, 4, 128, generator=torch.Generator().manual_seed(5)).cuda()
+    # (an active reducer keeps the generator-step forward out of the discriminator phase's pass, config.CFG.g_pair: the reducer-less
+    # reference run must launch the same kernels for a bit-for-bit comparison)
+    monkeypatch.setattr(CFG, "g_pair", False)
 
     def run(reducer):
         G, D, V = build(4, 1)
@@ -276,7 +281,7 @@ def test_eager_group_hooks_reduce_every_gradient_exactly_once():
             assert torch.equal(got[n], ref[n] * 0.5), (tag, n)
 
 
-def test_multi_gpu_code_path_in_a_one_rank_rccl_group():
+def test_multi_gpu_code_path_in_a_one_rank_rccl_group(monkeypatch):
     """Row e on one GPU: a real RCCL process group of ONE rank with the reducer kept live (single_rank_passthrough=False), so the
     side stream, the events, the in-place bucketed all-reduce of the flat gradient buffers, the group hooks of the eager
     backward and the three-graph replay all run - the collective itself is the identity, so every result must be bit-identical
@@ -286,6 +291,7 @@ def test_multi_gpu_code_path_in_a_one_rank_rccl_group():
     ops.set_compute_dtype(torch.float32)
     batches = gu.golden_batches(4, 1)
     noise = torch.randn(4, 4, 128, generator=torch.Generator().manual_seed(2)).cuda()
+    monkeypatch.setattr(CFG, "g_pair", False)         # as above: the same kernels with and without the reducer
 
     def run(reducer, graphed):
         G, D, V = build(4, 1)
