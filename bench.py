@@ -616,9 +616,23 @@ def bf16_parity_record(dev, tag="step_cf1_b2_seed0", dtype_name="bf16"):
     del mw
     gc.collect()
     torch.cuda.empty_cache()
+    # what 16-bit storage costs by itself: the CPU oracle with every layer output, gradient and normalised weight rounded to the storage
+    # type (oracle.set_storage - no kernel involved) against the same goldens; the tests bound the GPU modes by 2x these figures
+    model = None
+    try:
+        tests_dir = os.path.join(ROOT, "tests")
+        if tests_dir not in sys.path:
+            sys.path.insert(0, tests_dir)
+        import golden_util
+        torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8)))
+        m = golden_util.storage_noise_model(tag, TORCH_DTYPE[dtype_name], 65536.0 if dtype_name == "fp16" else 1.0)
+        model = {"worst_loss_rel_err": round(max(m["loss_rel"]), 6), "worst_pixel_abs_err": round(max(m["pixel_max"]), 5),
+                 "pixel_rms_err": round(max(m["pixel_rms"]), 5)}
+    except Exception as exc:
+        model = {"error": "%s: %s" % (type(exc).__name__, exc)}
     return {"against": "reference goldens tests/golden/%s (cf=%s, batch %d, 2 iterations of the reference's own loop)" % (tag, meta["cf"], meta["batch_size"]),
             "worst_loss_rel_err": round(max(rec["loss_rel"]), 6), "worst_pixel_abs_err": round(max(rec["pixel_max"]), 5),
-            "pixel_rms_err": round(max(rec["pixel_rms"]), 5), "fp32_mode_bound": 1e-3,
+            "pixel_rms_err": round(max(rec["pixel_rms"]), 5), "fp32_mode_bound": 1e-3, "oracle_storage_noise_model": model,
             "note": "%s storage + %s MFMA + fp32 accumulate vs the fp32 reference; the fp32 parity mode meets 1e-3 (parity_mode record)" % (dtype_name, dtype_name)}
 
 

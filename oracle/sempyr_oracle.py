@@ -42,6 +42,44 @@ IMAGENET_STD = (0.229, 0.224, 0.225)
 
 
 # --------------------------------------------------------------------------------------
+# storage-noise model (tests only; default OFF = the exact fp32 restatement above all else)
+#
+# The HIP path's throughput modes keep activations, activation gradients and the packed weights W / sigma in a 16-bit storage
+# type and accumulate in fp32.  ``set_storage(torch.bfloat16)`` makes THIS oracle round the same quantities to that type - every
+# layer output and its gradient, every normalised weight - while all arithmetic stays fp32: a noise model of 16-bit storage that is
+# independent of any kernel.  tests/test_gpu_step.py derives the bounds of the bf16 / fp16 modes from it (the error of this
+# model against the fp32 goldens, times a stated factor) instead of from a past measurement of the kernels themselves.
+# --------------------------------------------------------------------------------------
+_STORAGE: List[Optional[torch.dtype]] = [None]
+_GRAD_SCALE = [1.0]
+
+
+def set_storage(dtype: Optional[torch.dtype], grad_scale: float = 1.0) -> None:
+    """None: exact fp32 (the oracle proper).  torch.bfloat16 / torch.float16: the storage-noise model; grad_scale = the loss scale the
+    gradients carry while they are stored (the fp16 mode's 2^16: without it they underflow)."""
+    _STORAGE[0] = dtype
+    _GRAD_SCALE[0] = float(grad_scale)
+
+
+class _StoreFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype, gscale):
+        ctx.dtype, ctx.gscale = dtype, gscale
+        return x.to(dtype).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g * ctx.gscale).to(ctx.dtype).to(torch.float32) / ctx.gscale, None, None
+
+
+def st_(x: torch.Tensor) -> torch.Tensor:
+    """x as the 16-bit storage of the noise model holds it (identity in the oracle proper)."""
+    if _STORAGE[0] is None or not x.is_floating_point():
+        return x
+    return _StoreFn.apply(x, _STORAGE[0], _GRAD_SCALE[0])
+
+
+# --------------------------------------------------------------------------------------
 # spectral normalisation  (torch.nn.utils.spectral_norm, call sites models.py:28,34,55,...)
 # --------------------------------------------------------------------------------------
 def sn_weight(S: State, prefix: str, training: bool) -> torch.Tensor:
@@ -62,24 +100,24 @@ def sn_weight(S: State, prefix: str, training: bool) -> torch.Tensor:
         u = u.clone()
         v = v.clone()
     sigma = torch.dot(u, torch.mv(wm, v))
-    return w / sigma
+    return st_(w / sigma)
 
 
 def sn_linear(S: State, prefix: str, x: torch.Tensor, training: bool) -> torch.Tensor:
-    return F.linear(x, sn_weight(S, prefix, training), S[prefix + ".bias"])
+    return st_(F.linear(x, sn_weight(S, prefix, training), S[prefix + ".bias"]))
 
 
 def sn_conv(S: State, prefix: str, x: torch.Tensor, training: bool, padding: int) -> torch.Tensor:
-    return F.conv2d(x, sn_weight(S, prefix, training), S[prefix + ".bias"], stride=1, padding=padding)
+    return st_(F.conv2d(x, sn_weight(S, prefix, training), S[prefix + ".bias"], stride=1, padding=padding))
 
 
 def lrelu(x: torch.Tensor) -> torch.Tensor:
-    return F.leaky_relu(x, LRELU_SLOPE)
+    return st_(F.leaky_relu(x, LRELU_SLOPE))
 
 
 def upsample2(x: torch.Tensor) -> torch.Tensor:
     # nn.UpsamplingBilinear2d(scale_factor=2) == bilinear, align_corners=True (models.py:52,298,308)
-    return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    return st_(F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True))
 
 
 # --------------------------------------------------------------------------------------
@@ -104,7 +142,7 @@ def conditional_batch_norm(S: State, prefix: str, x: torch.Tensor, class_id: tor
     emb = S[prefix + ".embedding.weight"][class_id.argmax(dim=-1)]
     c = x.shape[1]
     scale, bias = emb[:, :c], emb[:, c:]
-    return scale[:, :, None, None] * y + bias[:, :, None, None]
+    return st_(scale[:, :, None, None] * y + bias[:, :, None, None])
 
 
 # --------------------------------------------------------------------------------------
@@ -120,9 +158,9 @@ def self_attention(S: State, prefix: str, x: torch.Tensor, training: bool) -> to
     k = k.reshape(b, c // 8, h * w // 4)                      # (B, C/8, HW/4)
     v = v.reshape(b, c // 2, h * w // 4)                      # (B, C/2, HW/4)
     attn = torch.softmax(torch.bmm(q, k), dim=-1)             # no 1/sqrt(d) scale (models.py:266)
-    o = torch.bmm(v, attn.transpose(1, 2)).reshape(b, c // 2, h, w)
+    o = st_(torch.bmm(v, attn.transpose(1, 2)).reshape(b, c // 2, h, w))
     o = sn_conv(S, prefix + ".attention_convolution", o, training, 0)
-    return S[prefix + ".gamma"] * o + x
+    return st_(S[prefix + ".gamma"] * o + x)
 
 
 # --------------------------------------------------------------------------------------
@@ -131,7 +169,7 @@ def self_attention(S: State, prefix: str, x: torch.Tensor, training: bool) -> to
 def linear_block(S: State, prefix: str, x: torch.Tensor, masked_feature: torch.Tensor,
                  training: bool) -> torch.Tensor:
     main = sn_linear(S, prefix + ".main_block.1", lrelu(x), training)
-    return main + sn_linear(S, prefix + ".masked_feature_mapping", masked_feature, training)
+    return st_(main + sn_linear(S, prefix + ".masked_feature_mapping", masked_feature, training))
 
 
 def generator_residual_block(S: State, prefix: str, x: torch.Tensor, feature: torch.Tensor,
@@ -142,7 +180,7 @@ def generator_residual_block(S: State, prefix: str, x: torch.Tensor, feature: to
     m = sn_conv(S, prefix + ".main_block.6", lrelu(m), training, 1)
     r = sn_conv(S, prefix + ".residual_mapping.1", upsample2(x), training, 0)
     f = sn_conv(S, prefix + ".masked_feature_mapping", feature, training, 1)
-    return (m + r) + f
+    return st_((m + r) + f)
 
 
 def generator_forward(S: State, z: torch.Tensor, features: Sequence[torch.Tensor],
@@ -164,10 +202,10 @@ def generator_forward(S: State, z: torch.Tensor, features: Sequence[torch.Tensor
             x = generator_residual_block(S, p, x, f, class_id, training)
             d -= 1
     x = upsample2(x)
-    x = batch_norm(S, "final_block.1", x, training, 0.1, affine=True)
+    x = st_(batch_norm(S, "final_block.1", x, training, 0.1, affine=True))
     x = sn_conv(S, "final_block.3", lrelu(x), training, 1)
     x = sn_conv(S, "final_block.5", lrelu(x), training, 0)
-    return torch.tanh(x)
+    return st_(torch.tanh(x))
 
 
 # --------------------------------------------------------------------------------------
@@ -177,8 +215,8 @@ def discriminator_input_block(S: State, p: str, x: torch.Tensor, training: bool)
     """DiscriminatorInputResidualBlock.forward (models.py:408-419)."""
     m = sn_conv(S, p + ".main_block.0", x, training, 1)
     m = sn_conv(S, p + ".main_block.2", lrelu(m), training, 1)
-    r = sn_conv(S, p + ".residual_mapping", F.avg_pool2d(x, 2), training, 0)
-    return F.avg_pool2d(m, 2) + r
+    r = sn_conv(S, p + ".residual_mapping", st_(F.avg_pool2d(x, 2)), training, 0)
+    return st_(F.avg_pool2d(m, 2) + r)
 
 
 def discriminator_residual_block(S: State, p: str, x: torch.Tensor, training: bool) -> torch.Tensor:
@@ -186,7 +224,7 @@ def discriminator_residual_block(S: State, p: str, x: torch.Tensor, training: bo
     m = sn_conv(S, p + ".main_block.1", lrelu(x), training, 1)
     m = sn_conv(S, p + ".main_block.3", lrelu(m), training, 1)
     r = sn_conv(S, p + ".residual_mapping", x, training, 0)
-    return F.avg_pool2d(m + r, 2)
+    return st_(F.avg_pool2d(m + r, 2))
 
 
 def discriminator_forward(S: State, x: torch.Tensor, class_id: torch.Tensor,
@@ -197,7 +235,7 @@ def discriminator_forward(S: State, x: torch.Tensor, class_id: torch.Tensor,
         p = "layers.%d" % i
         x = self_attention(S, p, x, training) if i == 3 else discriminator_residual_block(S, p, x, training)
     x = lrelu(x)
-    x = F.adaptive_avg_pool2d(x, 1).flatten(1)
+    x = st_(F.adaptive_avg_pool2d(x, 1).flatten(1))
     x = lrelu(sn_linear(S, "layers.11", x, training))                       # (B, 128)
     emb_w = sn_weight(S, "embedding", training)                             # SN on the embedding too
     emb = emb_w[class_id.argmax(dim=-1, keepdim=True)]                      # (B, 1, 128)
@@ -212,7 +250,7 @@ def discriminator_forward(S: State, x: torch.Tensor, class_id: torch.Tensor,
 def vgg16_forward(S: State, x: torch.Tensor) -> List[torch.Tensor]:
     mean = torch.tensor(IMAGENET_MEAN, dtype=x.dtype)[None, :, None, None]
     std = torch.tensor(IMAGENET_STD, dtype=x.dtype)[None, :, None, None]
-    x = (x - mean) / std
+    x = st_((x - mean) / std)
     feats = []
     idx = 0
     for v in VGG_CFG:
@@ -222,17 +260,17 @@ def vgg16_forward(S: State, x: torch.Tensor) -> List[torch.Tensor]:
             idx += 1
         else:
             p = "vgg16.features.%d" % idx
-            x = F.relu(F.conv2d(x, S[p + ".weight"], S[p + ".bias"], padding=1))
+            x = st_(F.relu(F.conv2d(x, st_(S[p + ".weight"]), S[p + ".bias"], padding=1)))
             idx += 2
-    x = F.adaptive_avg_pool2d(x, (7, 7)).flatten(1)
-    x = F.relu(F.linear(x, S["vgg16.classifier.0.weight"], S["vgg16.classifier.0.bias"]))
+    x = st_(F.adaptive_avg_pool2d(x, (7, 7)).flatten(1))
+    x = st_(F.relu(F.linear(x, st_(S["vgg16.classifier.0.weight"]), S["vgg16.classifier.0.bias"])))
     # models.py:212 appends the output of classifier[3] (the Linear), but classifier[4] is torchvision's
     # nn.ReLU(inplace=True) and eval-mode Dropout returns its input, so the tapped tensor is overwritten
     # in place: the 4096-d feature the generator and the reconstruction loss see is POST-ReLU.
     # (Pinned by golden step_cf1_b2_seed0 iteration 1, whose sample 0 unmasks this level.)
-    x = F.relu(F.linear(x, S["vgg16.classifier.3.weight"], S["vgg16.classifier.3.bias"]))
+    x = st_(F.relu(F.linear(x, st_(S["vgg16.classifier.3.weight"]), S["vgg16.classifier.3.bias"])))
     feats.append(x)
-    x = F.linear(x, S["vgg16.classifier.6.weight"], S["vgg16.classifier.6.bias"])
+    x = st_(F.linear(x, st_(S["vgg16.classifier.6.weight"]), S["vgg16.classifier.6.bias"]))
     feats.append(x)
     return feats
 

@@ -72,3 +72,32 @@ def grad_samples(grads):
     return torch.cat([g.flatten()[fixed_indices(g.numel(), N_GRAD, j)] if g.numel() >= N_GRAD else
                       torch.cat([g.flatten(), torch.zeros(N_GRAD - g.numel())])
                       for j, g in enumerate(grads)]).double().cpu().numpy()
+
+
+def storage_noise_model(tag, dtype, grad_scale=1.0):
+    """The errors the ORACLE'S 16-bit storage-noise model (oracle.set_storage: every layer output, its gradient and every normalised
+    weight rounded to `dtype`, arithmetic in fp32 - no kernel involved) shows against the reference goldens of `tag` over the two
+    iterations of the loop: {loss_rel, pixel_max, pixel_rms} per iteration, the same statistics the 16-bit GPU modes are measured by.
+    What a correct implementation of 16-bit storage may lose is a realisation of this noise; the tests bound the GPU's errors by a
+    stated multiple of the model's."""
+    meta, arr = load(tag)
+    Gsd, Dsd, Vsd = synth_states(meta)
+    G, D, V = O.make_state(Gsd), O.make_state(Dsd), O.make_state(Vsd, frozen=True)
+    og, od = torch.optim.Adam(O.trainable(G), lr=meta["lr"]), torch.optim.Adam(O.trainable(D), lr=meta["lr"])
+    noise = torch.from_numpy(arr["noise"])
+    names = (("loss_discriminator_real", "loss_d_real"), ("loss_discriminator_fake", "loss_d_fake"), ("loss_generator", "loss_g"),
+             ("loss_generator_semantic_reconstruction", "loss_rec"), ("loss_generator_diversity", "loss_div"))
+    pix_idx = fixed_indices(meta["batch_size"] * 3 * 256 * 256, N_PIX, 0)
+    rec = {"loss_rel": [], "pixel_max": [], "pixel_rms": []}
+    O.set_storage(dtype, grad_scale)
+    try:
+        for it, (images, labels, masks) in enumerate(golden_batches(meta["batch_size"], meta["seed"])):
+            out = O.train_step(G, D, V, og, od, images, labels, masks, noise[2 * it], noise[2 * it + 1], skip_dead_d_wgrad=True)
+            rec["loss_rel"].append(max(abs(float(out[r]) - meta[n][it]) / max(abs(meta[n][it]), 2e-2) for n, r in names))
+            fake = out["images_fake_g"].detach().float().contiguous().flatten()[pix_idx].numpy()
+            ref = arr["fake_samples"][2 * it + 1]
+            rec["pixel_max"].append(float(np.abs(fake - ref).max()))
+            rec["pixel_rms"].append(float(np.sqrt(np.mean((fake - ref) ** 2))))
+    finally:
+        O.set_storage(None)
+    return rec

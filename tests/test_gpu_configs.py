@@ -157,9 +157,21 @@ def test_batch_20_full_step_vs_oracle_fp32():
     oracle in the fp32 parity mode: five losses and 4096 generator pixels of one full D+G step within the north-star's 1e-3
     (the B = 20 / B = 32 steps above are property checks only).  The oracle step takes ~15-25 s on the box's host cores;
     bench.py reports the same comparison in its line (`parity_b20`)."""
+    _full_step_vs_oracle_fp32(1, 41)
+
+
+def test_batch_20_full_step_vs_oracle_fp32_channel_factor_half():
+    """Round-4 VERDICT (next #7): BASELINE.json config 4's wide networks (channel_factor 0.5: 1024-channel generator stages, a 1536-channel
+    discriminator tail, /root/reference/models.py:34-48,117-128) at the benchmark's batch of 20, one full D+G step end to end against
+    the CPU oracle in the fp32 parity mode - five losses and 4096 generator pixels within 1e-3 (the oracle step is ~3x the cf = 1
+    one: about a minute on the box's host cores)."""
+    _full_step_vs_oracle_fp32(0.5, 43)
+
+
+def _full_step_vs_oracle_fp32(cf, seed):
     ops.set_compute_dtype(torch.float32)
     torch.set_num_threads(min(16, torch.get_num_threads()))
-    (G, D, V), (Gsd, Dsd, Vsd) = build(1, 41)
+    (G, D, V), (Gsd, Dsd, Vsd) = build(cf, seed)
     oG, oD, oV = O.make_state(Gsd), O.make_state(Dsd), O.make_state(Vsd, frozen=True)
     images, labels, masks = synthetic.synthetic_batch(20, 3)
     g = torch.Generator().manual_seed(77)

@@ -2,8 +2,8 @@
 reference's own ModelWrapper.train() loop (tests/golden/, see make_golden.py) and against the CPU oracle.
 
 Tolerances (north_star): <= 1e-3 relative on generator pixels and loss scalars in fp32 mode.  The bf16 mode
-(bf16 storage, bf16 MFMA, fp32 accumulate) is held to 2x its MEASURED error against the same goldens (BF16_MEASURED below:
-losses ~1.3e-3 relative, pixels 3.3e-2 absolute at the worst of 4096 samples, 6.3e-3 rms)."""
+(bf16 storage, bf16 MFMA, fp32 accumulate) is held to 2x what the ORACLE's storage-noise model of bf16 loses against the same goldens
+(NOISE_FACTOR below; model: losses ~1.1e-3 relative, pixels 3.1e-2 absolute at the worst of 4096 samples, 6.4e-3 rms)."""
 import os
 
 import numpy as np
@@ -135,29 +135,40 @@ def bf16_step_errors(tag, graphed=False):
     return rec
 
 
-# measured on MI355X (round 3, printed by the test below; bf16 storage + bf16 MFMA, fp32 accumulate, vs the fp32 reference):
-#   tag                 worst loss error (relative, floor 2e-2)   worst pixel error   pixel rms
-BF16_MEASURED = {"step_cf1_b2_seed0": (1.3e-3, 3.3e-2, 6.3e-3), "step_cf4_b4_seed1": (1.0e-3, 3.4e-2, 6.3e-3)}
+# What 16-bit storage may cost is not a past measurement of these kernels but a property of the arithmetic: the ORACLE's
+# storage-noise model (oracle.set_storage / golden_util.storage_noise_model: the CPU restatement with every layer output, its
+# gradient and every normalised weight rounded to the storage type, fp32 arithmetic - no kernel involved) against the same goldens.
+# Evaluated in the build container: bf16 cf=1 losses 1.1e-3, pixels 3.1e-2 worst / 6.4e-3 rms (cf=4: 9.7e-4 / 3.9e-2 / 6.3e-3);
+# the kernels measured 1.3e-3 / 3.3e-2 / 6.3e-3 in round 3 and 6.2e-4 / 3.8e-2 / 6.4e-3 in round 4 - the bf16 mode's error IS
+# the storage noise.  A GPU run is one realisation of that noise, the model another (other rounding points: the kernels fuse
+# activation / residual / pooling into one rounding where the model rounds after every primitive), and the worst of 4096 pixels
+# is a tail statistic: the bound is NOISE_FACTOR x the model's figure, computed at test time.
+NOISE_FACTOR = 2.0
+
+
+def assert_within_storage_noise(rec, model, what):
+    for key in ("loss_rel", "pixel_max", "pixel_rms"):
+        got, allowed = max(rec[key]), NOISE_FACTOR * max(model[key])
+        assert got <= allowed, "%s: %s %.3e > %.1f x the oracle's storage-noise model %.3e" % (what, key, got, NOISE_FACTOR, max(model[key]))
 
 
 @pytest.mark.parametrize("tag", ["step_cf1_b2_seed0", "step_cf4_b4_seed1"])
 def test_train_step_bf16_restated_tolerance(tag):
-    """The THROUGHPUT mode (what bench.py times) against the reference goldens, incl. the benchmark's own channel_factor = 1.
-    The bound is 2x the MEASURED error (BF16_MEASURED above; the measurement is printed and written to
-    gpurun_out/bf16_parity_<tag>.json on every run), not a guess: bf16 has 8 mantissa bits, the reference is fp32 end to end."""
+    """The THROUGHPUT mode (what bench.py times) against the reference goldens, incl. the benchmark's own channel_factor = 1, bounded
+    by the oracle's own noise model of bf16 storage (above) - bf16 has 8 mantissa bits, the reference is fp32 end to end; the
+    measurement and the model are printed and written to gpurun_out/bf16_parity_<tag>.json on every run."""
     import json
     import os
     rec = bf16_step_errors(tag)
-    print("bf16 vs reference goldens, %s: %s" % (tag, json.dumps(rec)))
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    model = gu.storage_noise_model(tag, torch.bfloat16)
+    print("bf16 vs reference goldens, %s: %s; oracle storage-noise model: %s" % (tag, json.dumps(rec), json.dumps(model)))
     try:
         os.makedirs("gpurun_out", exist_ok=True)
-        json.dump(rec, open(os.path.join("gpurun_out", "bf16_parity_%s.json" % tag), "w"))
+        json.dump({"measured": rec, "oracle_storage_noise_model": model}, open(os.path.join("gpurun_out", "bf16_parity_%s.json" % tag), "w"))
     except OSError:
         pass
-    loss, pix, rms = BF16_MEASURED[tag]
-    assert max(rec["loss_rel"]) <= 2 * loss, rec
-    assert max(rec["pixel_max"]) <= 2 * pix, rec
-    assert max(rec["pixel_rms"]) <= 2 * rms, rec
+    assert_within_storage_noise(rec, model, "bf16 " + tag)
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])

@@ -96,3 +96,17 @@ def test_mask_generator_statistics_match_the_reference_generator():
     # the closed-form probabilities of misc.py:28-34: stage ~ choice([0..6, 0, 1]), spatial with p = 0.3 for 0 < stage < 6
     spatial = sum(c for (s, sp), c in counts.items() if sp) / n
     assert abs(spatial - 0.3 * 6 / 9) < 0.01
+
+
+def test_storage_noise_model_is_neither_vacuous_nor_exact():
+    """oracle.set_storage (the 16-bit storage-noise model the bf16 / fp16 GPU tests take their bounds from, tests/test_gpu_step.py):
+    off, the oracle reproduces the goldens as before; on, it loses what 8 (bf16) / 11 (fp16 with the loss scale) significant bits
+    lose - pinned to a window, so that a model that stopped rounding (a bound of zero) or rounds wildly (a vacuous bound) fails here."""
+    tag = "step_cf4_b4_seed1"
+    exact = gu.storage_noise_model(tag, None)
+    assert max(exact["pixel_max"]) <= 1e-4 and max(exact["loss_rel"]) <= 1e-5, exact
+    bf = gu.storage_noise_model(tag, torch.bfloat16)
+    assert 2e-3 <= max(bf["pixel_rms"]) <= 2e-2 and 1e-4 <= max(bf["loss_rel"]) <= 5e-3 and max(bf["pixel_max"]) <= 0.12, bf
+    h = gu.storage_noise_model(tag, torch.float16, 65536.0)
+    assert 2e-4 <= max(h["pixel_rms"]) <= 4e-3 and max(h["pixel_max"]) <= 3e-2, h
+    assert max(h["pixel_rms"]) < 0.4 * max(bf["pixel_rms"])
