@@ -1053,9 +1053,23 @@ int launch_tall(const sp_conv_params& p, hipStream_t s) {
     return SP_OK;
 }
 
-// number of K splits for `tiles` output tiles and nk K-steps: aim at ~2.5 blocks per CU, at least 6 K-steps per split
+// Output tile of the LDS-DMA igemm on small-spatial layers with Cout > 64 (SP_TUNE_IGEMM_TILE: 0 = 64 co x 64 px, 1 = 128 x 128,
+// 2 = 128 co x 64 px, 3 = 64 co x 128 px).  64 x 64 is the fastest form almost everywhere (round 5, scratch/ab_small_tile.py: these
+// launches are latency-bound, larger tiles do not pay by themselves) - except where its tile count lands between one and two rounds
+// of the 256 CUs and K is long: 512 -> 512 on 8 x 8 maps at batch 40 has 320 tiles of 72 K-steps each (no split: 1.25 rounds, 36.5
+// us); 160 tiles of 128 co x 64 px split K three ways (480 blocks of 24 steps: 28.3 us).
+inline int igemm_small_tile(long M, int cout, int cin_p, int ksize, int dtype) {
+    const int forced = sp_tune(SP_TUNE_IGEMM_TILE, -1);
+    if (forced >= 0) return forced;
+    const long tiles64 = ((M + 63) / 64) * ((cout + 63) / 64);
+    const int e = dtype == SP_F32 ? 4 : 8;
+    const int nk = ksize * ksize * ((cin_p + 8 * e - 1) / (8 * e));
+    return (tiles64 > 256 && tiles64 <= 512 && nk >= 48 && cout % 128 == 0) ? 2 : 0;
+}
+
+// number of K splits for `tiles` output tiles and nk K-steps: aim at ~1.5 blocks per CU, at least 6 K-steps per split
 inline int split_k_plan(int tiles, int nk) {
-    const int target = sp_tune(SP_TUNE_SPLITK_TARGET, 640);
+    const int target = sp_tune(SP_TUNE_SPLITK_TARGET, 384);          // (round 5: 640 -> 384, 5 - 10 % on the 4 x 4 / 8 x 8 layers; scratch/ab_small_tile.py)
     int min_steps = sp_tune(SP_TUNE_SPLITK_MINSTEPS, 6);
     if (min_steps < 1) min_steps = 1;
     if (tiles > 256 || nk < 16) return 1;           // more tiles than CUs: a split only adds the finalize pass (measured)
@@ -1621,7 +1635,14 @@ int dispatch(const sp_conv_params& p, hipStream_t s) {
     if (p.cout > 16 && dma_fits && (dma_mode == 2 || (dma_mode == 1 && p.ksize == 3 && M <= 8192))) {
         if (p.cout <= 32) return launch_dma<T, 1, 4, 2, 4>(p, s);        //  32 co x 256 px
         if (p.cout <= 64) return launch_dma<T, 1, 4, 4, 4>(p, s);        //  64 co x 256 px
-        if (M <= 8192) return launch_dma<T, 2, 2, 2, 2>(p, s);           //  64 co x  64 px
+        if (M <= 8192) {
+            switch (igemm_small_tile(M, p.cout, p.cin_p, p.ksize, p.dtype)) {
+                case 1: return launch_dma<T, 2, 2, 4, 4>(p, s);          // 128 co x 128 px
+                case 2: return launch_dma<T, 2, 2, 4, 2>(p, s);          // 128 co x  64 px
+                case 3: return launch_dma<T, 2, 2, 2, 4>(p, s);          //  64 co x 128 px
+                default: return launch_dma<T, 2, 2, 2, 2>(p, s);         //  64 co x  64 px
+            }
+        }
         return launch_dma<T, 2, 2, 4, 4>(p, s);                          // 128 co x 128 px
     }
     if (p.cout <= 16) return launch_cfg<T, 1, 4, 1, 4>(p, s);            //  16 co x 256 px
@@ -1642,7 +1663,12 @@ extern "C" int sp_conv2d_workspace(int32_t n, int32_t h, int32_t w_, int32_t cin
     const int dma_mode = sp_tune(SP_TUNE_IGEMM_DMA, 1);
     const bool halo_path = ksize == 3 && cout > 32 && h % HALO_TH == 0 && w_ % HALO_TW == 0;
     if (ksize != 3 || halo_path || cout <= 16 || M > 8192 || dma_mode == 0) return SP_OK;
-    const int co_t = cout <= 32 ? 32 : 64, px_t = cout <= 64 ? 256 : 64;
+    int co_t = cout <= 32 ? 32 : 64, px_t = cout <= 64 ? 256 : 64;
+    if (cout > 64) {                                                     // (the tile dispatch() picks for these layers)
+        const int tile = igemm_small_tile(M, cout, cin_p, ksize, dtype);
+        if (tile == 1 || tile == 2) co_t = 128;
+        if (tile == 1 || tile == 3) px_t = 128;
+    }
     const int tiles = (int)((M + px_t - 1) / px_t) * ((cout + co_t - 1) / co_t);
     const int e = dtype == SP_F32 ? 4 : 8;
     const int nk = 9 * ((cin_p + 8 * e - 1) / (8 * e));
