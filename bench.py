@@ -654,11 +654,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # BENCH_ONE_DEVICE=1 + BENCH_DIST_BACKEND=gloo: every rank on cuda:0, gloo between them - the dry run of the N > 1 code path on a
+    # one-GPU box (tests/test_gpu_two_ranks.py; RCCL refuses two ranks on one device).  Never a measurement.
+    one_device = os.environ.get("BENCH_ONE_DEVICE", "0") == "1"
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         dist.barrier()                               # creates the communicator now: RCCL prints its version banner here ...
         flush_c_stdio()                              # ... through C stdio - push it out BEFORE the JSON line, not at exit
 
@@ -697,7 +706,8 @@ def main():
             "config": {"workload": "Semantic-Pyramid GAN D+G step, channel_factor=%g, 256x256x3, batch %d/GPU, Adam lr 1e-5, "
                                    "random-init G/D, kaiming-init frozen VGG-16" % (cf, args.batch),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                       "launch": launch_mode, "deterministic": bool(args.deterministic or args.dtype == "f32"), "masks": "fresh on-device batch per step" if args.device_masks else "one resident batch",
+                       "launch": launch_mode, "collectives": (backend + (", every rank on one device: a dry run, not a measurement" if one_device else "")) if world > 1 else None,
+                       "deterministic": bool(args.deterministic or args.dtype == "f32"), "masks": "fresh on-device batch per step" if args.device_masks else "one resident batch",
                        "losses_last_step": losses},
             "roofline": {"bound": "mfma", "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None, "traffic": None,
                          "basis": "achieved / frac: the DOMINANT KERNEL alone (dominant_kernel: algorithmic FLOPs of its launches / their "

@@ -134,18 +134,20 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const T* __restrict__
 // the layer's epilogue, for launches whose single K-split finishes the layer itself (y != nullptr: no slab, no finalize pass)
 struct LinTail { const float* bias; const bf16* res; bf16* y; int ldy, act; };
 
-template <int LM_KS>
+// NB = 16-row batch fragments per block: 2 (up to 32 rows) or 4 (up to 64 - round 5: the two-batch VGG-16 pass hands its 40 / 64 rows
+// over in ONE launch, so FC1's 205 MB of weights are streamed once instead of once per group)
+template <int LM_KS, int NB = 2>
 __global__ __launch_bounds__(256) void linear_mfma_kernel(const bf16* __restrict__ x, int ldx, const bf16* __restrict__ wp, int kp,
                                                           float* __restrict__ acc_out, int B, int K, int N, LinTail tail) {
     constexpr int LM_PITCH = LM_KS * 2 + 16;
-    extern __shared__ __attribute__((aligned(16))) char xs_raw[];     // [32][LM_PITCH bytes]
+    extern __shared__ __attribute__((aligned(16))) char xs_raw[];     // [16 * NB][LM_PITCH bytes]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * 128 + wave * 32;
     const int k0 = blockIdx.y * LM_KS;
     const int klen = min(LM_KS, kp - k0);                            // multiple of 8 (kp is)
-    // stage x[0..32)[k0..k0+klen) (zero padded)
+    // stage x[0..16 NB)[k0..k0+klen) (zero padded)
     const bool vec = ((ldx & 7) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-    for (int e = tid; e < 32 * (LM_KS / 8); e += 256) {
+    for (int e = tid; e < 16 * NB * (LM_KS / 8); e += 256) {
         const int b = e / (LM_KS / 8), kc = (e - b * (LM_KS / 8)) * 8;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (b < B && kc < klen) {
@@ -162,11 +164,11 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const bf16* __restrict
     }
     __syncthreads();
     const int frow = lane & 15, g = lane >> 4;
-    f32x4_t acc[2][2];
+    f32x4_t acc[2][NB];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NB; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const bf16* wrow[2];
     bool wok[2];
 #pragma unroll
@@ -194,14 +196,14 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const bf16* __restrict
         for (int u = 0; u < U; ++u) {
             const int kk = kk0 + u;
             if (kk * 32 >= klen) break;
-            uint4 bx[2];
+            uint4 bx[NB];
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NB; ++j)
                 bx[j] = *reinterpret_cast<const uint4*>(xs_raw + (j * 16 + frow) * LM_PITCH + (kk * 32 + g * 8) * 2);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NB; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[i][u]), __builtin_bit_cast(bf16x8_t, bx[j]),
                                                                         acc[i][j], 0, 0, 0);
         }
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const bf16* __restrict
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NB; ++j) {
             const int b = j * 16 + (lane & 15);
             if (b >= B) continue;
 #pragma unroll
@@ -252,15 +254,22 @@ __global__ void linear_finalize_kernel(const float* __restrict__ acc, int nsplit
 // bias / residual / activation from its registers and the finalize launch - ~5 us of queue time, as much as the layer itself - is gone
 // (the latent / linear-block 128 -> 128 layers, D's 768 -> 128, the 365 -> 128 class mapping and their input gradients).
 static inline int linear_ks(int kp) { return kp > 8192 ? 1024 : (kp >= 2048 ? 512 : (kp > 1024 ? 128 : (kp > 512 ? 1024 : (kp > 128 ? 512 : 128)))); }
-static inline bool linear_use_mfma(int dtype, int batch, int k, int n) { return dtype == SP_BF16 && batch <= 32 && (long)k * n >= (1L << 12); }
+static inline bool linear_use_mfma(int dtype, int batch, int k, int n) { return dtype == SP_BF16 && batch <= 64 && (long)k * n >= (1L << 12); }
+
+template <int KS, int NB>
+static void launch_linear_mfma_nb(dim3 grid, hipStream_t s, const bf16* x, int ldx, const bf16* w, int kp, float* scratch, int batch, int k, int n,
+                                  const LinTail& tail) {
+    static bool a = false;
+    const int lds = 16 * NB * (KS * 2 + 16);
+    if (!a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_mfma_kernel<KS, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); a = true; }
+    hipLaunchKernelGGL((linear_mfma_kernel<KS, NB>), grid, dim3(256), lds, s, x, ldx, w, kp, scratch, batch, k, n, tail);
+}
 
 template <int KS>
 static void launch_linear_mfma(dim3 grid, hipStream_t s, const bf16* x, int ldx, const bf16* w, int kp, float* scratch, int batch, int k, int n,
                                const LinTail& tail) {
-    static bool a = false;
-    const int lds = 32 * (KS * 2 + 16);
-    if (!a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_mfma_kernel<KS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); a = true; }
-    hipLaunchKernelGGL(linear_mfma_kernel<KS>, grid, dim3(256), lds, s, x, ldx, w, kp, scratch, batch, k, n, tail);
+    if (batch <= 32) launch_linear_mfma_nb<KS, 2>(grid, s, x, ldx, w, kp, scratch, batch, k, n, tail);
+    else launch_linear_mfma_nb<KS, 4>(grid, s, x, ldx, w, kp, scratch, batch, k, n, tail);
 }
 
 extern "C" int sp_linear_fwd(const void* x, int32_t ldx, const void* w_packed, int32_t kp, const float* bias,

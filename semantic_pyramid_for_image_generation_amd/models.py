@@ -950,8 +950,9 @@ class _VGGPyramidFn(torch.autograd.Function):
 
         def lin(inp, pk, nout, act):
             out = torch.empty((n, nout), dtype=dtype, device=dev)
-            for lo in range(0, n, n_grad):                       # per group: the split-K MFMA form takes up to 32 rows
-                rows = min(n_grad, n - lo)
+            step = n if (n <= 64 and CFG.vgg_fc_joint) else n_grad   # (the split-K MFMA form takes up to 64 rows: both groups of a two-batch
+            for lo in range(0, n, step):                         # pass in one launch - the weights are streamed once; beyond: per group)
+                rows = min(step, n - lo)
                 ops.linear_launch(inp[lo:lo + rows], pk["fwd"].data_ptr(), pk["kp"], pk["bias"], None, out[lo:lo + rows], rows, inp.shape[1],
                                   nout, act)
             return out

@@ -1136,7 +1136,7 @@ def reused_layer(module, x_saved, y_prev, pl_prev: PackedLayer, dest: Optional[D
 def linear_launch(x, w_ptr: int, kp: int, bias, res, y, b: int, k: int, n: int, act: int) -> None:
     """y[b][n] = act(x W^T + bias + res); large bf16 matrices go through the MFMA split-K path (fp32 scratch)."""
     scratch = None
-    if is_16bit(x.dtype) and b <= 32:
+    if is_16bit(x.dtype) and b <= 64:
         key = (b, k, n)
         floats = _LIN_WS_CACHE.get(key)
         if floats is None:

@@ -270,6 +270,18 @@ def launch(out_path, world=2, timeout_s=900.0):
             os.remove("%s.rank%d.json" % (prefix, r))
         except (OSError, ValueError):
             merged["failures"].append("rank %d left no record (exit code %s)" % (r, p.returncode))
+    # bench.py's own N > 1 path (rank spawning, rendezvous, the reducer inside the timed loop, capture agreement, the max-over-ranks
+    # clock, comm_stats, the multi_gpu record) has no multi-GPU box to run on either: a dry run with two ranks on this GPU over gloo
+    try:
+        env = dict(os.environ, BENCH_ONE_DEVICE="1", BENCH_DIST_BACKEND="gloo", BENCH_RANK_TIMEOUT_S="600")
+        env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4",
+                              "--channel-factor", "8", "--no-cpu-baseline", "--no-sub-records", "--no-kernel-probe"],
+                             env=env, capture_output=True, text=True, timeout=900)
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        merged["bench_two_ranks"] = {"returncode": out.returncode, "line": json.loads(line[-1]) if line else None, "stderr_tail": out.stderr[-1500:]}
+    except Exception as exc:
+        merged["bench_two_ranks"] = {"returncode": -1, "line": None, "stderr_tail": "%s: %s" % (type(exc).__name__, exc)}
     tmp = out_path + ".tmp"
     with open(tmp, "w") as f:
         json.dump(merged, f, indent=1)

@@ -494,7 +494,9 @@ def test_conv_linearity_property_full_size():
 # ----------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [(128, 128, 2), (365, 2048, 4), (4096, 365, 3), (768, 128, 20), (512, 130, 20), (1000, 128, 32), (1024, 256, 7),
-                                  (136, 77, 5), (1536, 128, 20), (128, 16384, 20)])
+                                  (136, 77, 5), (1536, 128, 20), (128, 16384, 20),
+                                  # 33 .. 64 rows: the four-fragment form of the split-K MFMA kernel (round 5: both groups of the two-batch VGG pass)
+                                  (4096, 2048, 40), (365, 130, 48), (128, 128, 64), (2048, 1000, 33)])
 def test_sn_linear(case, dtype):
     """(16-bit storage: rows of up to 1024 values finish in one launch - the single K-split applies the epilogue itself -, longer
     rows go through slabs + the finalize pass: csrc/linear.hip)"""

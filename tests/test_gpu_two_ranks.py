@@ -39,3 +39,19 @@ def test_two_ranks_on_one_gpu_take_the_oracles_averaged_adam_steps():
             assert m["grad_norm_rel_err_d"] <= 1e-2 and m["grad_norm_rel_err_g"] <= 1e-2, (mode, m)
             assert m["param_norm_rel_err_d"] <= 1e-3 and m["param_norm_rel_err_g"] <= 1e-3, (mode, m)
     print("two-rank step: " + json.dumps({k: rec["ranks"][0][k] for k in ("eager", "graph")}))
+
+
+def test_bench_two_rank_dry_run_on_one_gpu():
+    """bench.py --gpus 2 with both ranks on this GPU and gloo between them (BENCH_ONE_DEVICE / BENCH_DIST_BACKEND; started by the same
+    GPU-clean launcher, after the step job): not a measurement - the first execution of bench.py's N > 1 code path anywhere: it spawns
+    its ranks, they rendezvous, agree on the launch mode, run the timed loop with the reducer's collectives, take the max-over-ranks
+    clock and rank 0 prints ONE line with the multi-GPU record."""
+    rec = _record().get("bench_two_ranks")
+    assert rec is not None, "the launcher did not run the bench dry run"
+    assert rec["returncode"] == 0 and rec["line"] is not None, rec
+    line = rec["line"]
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak" and line["config"]["global_batch"] == 8, line
+    mg = line["multi_gpu"]
+    assert len(mg["per_rank_images_per_sec"]) == 2 and all(v > 0 for v in mg["per_rank_images_per_sec"]), mg
+    assert mg["allreduce_ms_d"] is not None and mg["allreduce_ms_g"] is not None and mg["grad_bytes_d"] > 0 and mg["grad_bytes_g"] > 0, mg
+    assert abs(line["value"] - 8 * line["steps"] / (line["ms_per_step"] * line["steps"] / 1e3)) <= 0.02 * line["value"]
