@@ -29,3 +29,13 @@ rm -rf $OUT/trace_graph
 bash scratch/pmc_pp.sh r5_pp 1 128 128 128 20 > $OUT/pmc_pp.log 2>&1
 cp gpurun_out/pmc_r5_pp/summary.txt $OUT/pmc_conv3x3_pp_2_128x128_128px.txt
 ls -la $OUT
+
+# BASELINE.json config 4 on one GPU: kernel stats of the replayed step at channel_factor 0.5 and 2 (round-4 VERDICT, next #7)
+cd /tmp
+for CF in 0.5 2; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cf$CF -- python3 /root/repo/bench.py --channel-factor $CF --steps 8 --warmup 3 --no-sub-records --no-cpu-baseline --no-kernel-probe > $OUT/trace_cf${CF}_bench.json 2> $OUT/trace_cf$CF.err
+  cp $(ls $OUT/trace_cf$CF/*/*kernel_stats.csv | head -1) $OUT/kernel_stats_cf$CF.csv
+  rm -rf $OUT/trace_cf$CF
+done
+cd /root/repo
+ls -la $OUT

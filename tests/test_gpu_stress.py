@@ -344,3 +344,21 @@ def test_batch_norm_of_the_bilinear_expansion_random_shapes(dtype, tol):
         if max(same) > (1e-5 if dtype == torch.float32 else 2e-2):
             fails.append(("vs separate passes", n, c, h, w, act, cond, same))
     assert not fails, fails
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_maxpool_epilogue_with_positions_random_shapes(dtype):
+    """Round 5: conv3x3 -> ReLU -> MaxPool with recorded window positions (sp_conv_params.pool_idx / sp_maxpool2_bwd_idx) on random
+    shapes - channel counts that leave partial 64 / 128-channel tiles, Cin with a padded tail, every tile height, ties and not, the
+    ping-pong kernels switched off for a third of the cases (the LDS-DMA tall kernels then), fp32 / bf16 / fp16 storage - always BIT-
+    IDENTICAL to the unpooled tensor -> sp_maxpool2_fwd -> sp_maxpool2_bwd path (tests/test_gpu_ops.py holds the fixed cases)."""
+    import random
+    import test_gpu_ops as T
+    _seed(11)
+    for k in range(18):
+        cout = random.choice([48, 64, 80, 128, 144, 192, 256])
+        cin = random.choice([16, 24, 64, 72, 128])
+        if dtype == torch.float32:
+            cin = (cin + 3) // 4 * 4
+        n, h, w = random.randint(1, 4), random.choice([8, 16, 24, 32, 48]), random.choice([32, 64])
+        T.test_conv_maxpool_epilogue_records_the_window_positions((cin, cout, n, h, w, int(k % 3 == 2)), bool(k % 2), dtype)
