@@ -25,6 +25,7 @@ results beyond floating-point summation order.  The kernel library itself reads 
     vgg_pool_idx          SP_VGG_POOL_IDX        1        VGG-16 pass WITH gradient: a stage's last convolution stores the pooled output + 2-bit window positions instead of the unpooled tensor (sp_conv_params.pool_idx)
     g_pair                SP_G_PAIR              1        the generator's two forwards of an iteration (D step: no gradient; G step: with) as one two-group pass below 256 x 256 (models.Generator.forward_pair); off while a gradient reducer is active (the G-step forward is what hides D's all-reduce)
     vgg_fc_joint          SP_VGG_FC_JOINT        1        the VGG-16 classifier of a two-batch pass in one launch per layer (up to 64 rows: the weights are streamed once)
+    sn_skip_pack          SP_SN_SKIP_PACK        1        the second forward of a two-group pass does not write the packed copies its trunk never reads (ops.SpectralNormBank._unpacked_table)
     f16_loss_scale        SP_F16_LOSS_SCALE      65536    static loss scale of the fp16 storage mode (ops.set_compute_dtype(torch.float16))
     vgg_fp8               SP_VGG_FP8             0        BASELINE.json config 5's fp8 slice: VGG-16's wide 3x3 layers on the fp8 MFMA in the no-gradient pass (ops.set_vgg_fp8)
     lib_path              SEMPYR_LIB             (in-tree libsempyr.so)
@@ -62,6 +63,7 @@ class Config:
     g_pair: bool = True
     fuse_tail_grad: bool = True
     vgg_fc_joint: bool = True
+    sn_skip_pack: bool = True
 
     @classmethod
     def from_env(cls) -> "Config":
@@ -74,7 +76,8 @@ class Config:
                    fuse_upsample_bn=_flag("SP_FUSE_UPSAMPLE_BN", True), fuse_tail=_flag("SP_FUSE_TAIL", True),
                    wgrad_side_stream=int(os.environ.get("SP_WGRAD_SIDE_STREAM", "0")), reuse_feature_maps=_flag("SP_REUSE_FEATURE_MAPS", True), vgg_pair=_flag("SP_VGG_PAIR", True),
                    vgg_pool_idx=_flag("SP_VGG_POOL_IDX", True), g_pair=_flag("SP_G_PAIR", True),
-                   fuse_tail_grad=_flag("SP_FUSE_TAIL_GRAD", True), vgg_fc_joint=_flag("SP_VGG_FC_JOINT", True))
+                   fuse_tail_grad=_flag("SP_FUSE_TAIL_GRAD", True), vgg_fc_joint=_flag("SP_VGG_FC_JOINT", True),
+                   sn_skip_pack=_flag("SP_SN_SKIP_PACK", True))
 
 
 CFG = Config.from_env()

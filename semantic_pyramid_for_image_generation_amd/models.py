@@ -603,8 +603,17 @@ class Generator(nn.Module):
         n = input_g.shape[0]
         bank = self._bank
         dev = input_g.device
+        if getattr(self, "_pair_slots", None) is None:
+            # the convolutions of the joint stages take forward g's packing (+ the per-group scale): forward d does not pack them.  It
+            # keeps what runs per group on its own sigma: the linear trunk, the masked-feature mappings, the final block
+            joint = [self.convolution_layer[1]]
+            for m in self.main_path:
+                joint += ([m.query_convolution, m.key_convolution, m.value_convolution, m.attention_convolution] if isinstance(m, SelfAttention)
+                          else [m.main_block[3], m.main_block[6], m.residual_mapping[1]])
+            ids = {id(m) for m in joint}
+            self._pair_slots = frozenset(i for i, (m, _, _) in enumerate(bank.specs) if id(m) in ids)
         with torch.no_grad():
-            call_d = bank.begin(True, dt, dev)                 # forward #1: its own power iteration, no autograd handles
+            call_d = bank.begin(True, dt, dev, skip_pack=self._pair_slots if CFG.sn_skip_pack else None)   # forward #1: own power iteration, no autograd handles
         call_g = bank.begin(True, dt, dev)                     # forward #2
         handles_g = bank.handles
         scales = torch.empty(2 * len(bank.specs), dtype=torch.float32, device=dev)
@@ -749,7 +758,9 @@ class Discriminator(nn.Module):
             return self(input_a, class_id), self(input_b, class_id)
         bank = self._bank
         na = input_a.shape[0]
-        pair = bank.begin_pair(self.training, dt, input_a.device, na)
+        if getattr(self, "_trunk_slots", None) is None:      # every convolution runs on forward a's packing in the two-group pass
+            self._trunk_slots = frozenset(i for i, (m, _, _) in enumerate(bank.specs) if isinstance(m, SNConv2d))
+        pair = bank.begin_pair(self.training, dt, input_a.device, na, self._trunk_slots)
         try:
             L = self.layers
             x = L[0](ops.ingest_image_pair(input_a, input_b, dt))

@@ -579,7 +579,31 @@ class SpectralNormBank:
             self._make_views()
         self.bwd_table_dev = torch.frombuffer(bytearray(bytes(btab)), dtype=torch.uint8).to(device)
 
-    def begin(self, training: bool, dtype, device) -> SNCall:
+    def _unpacked_table(self, skip: frozenset):
+        """(device table, pack blocks) of a forward that packs every layer BUT those in `skip` (slots): the same entries with the
+        skipped layers' block ranges of the packing kernel's 1-D grid made empty - their slices of the pack arena stay unwritten.
+        For the second forward of a two-group pass, whose convolution trunk runs on the first forward's packing (begin_pair,
+        models.Generator.forward_pair): the power iteration and the (u, v, sigma) snapshot are per forward, the packed copy is not."""
+        cache = self.__dict__.setdefault("_nopack_tables", {})
+        hit = cache.get(skip)
+        if hit is not None and hit[2] is self._table_host:
+            return hit[0], hit[1]
+        n = len(self.specs)
+        tab = (L.SpSnLayer * n)()
+        ctypes.memmove(tab, self._table_host, ctypes.sizeof(tab))
+        blocks = 0
+        for i in range(n):
+            ent = self.entries[i]
+            width = (self.entries[i + 1].pack_block0 if i + 1 < n else self.pack_blocks) - ent.pack_block0
+            tab[i].pack_block0 = blocks
+            if i not in skip:
+                blocks += width
+        dev = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.table_dev.device)
+        cache[skip] = (dev, max(blocks, 1), self._table_host)
+        return dev, max(blocks, 1)
+
+    def begin(self, training: bool, dtype, device, skip_pack: Optional[frozenset] = None) -> SNCall:
+        """skip_pack: slots of layers whose packed weights this forward will not be asked for (_unpacked_table)."""
         key = (dtype, str(device)) + tuple((m.weight_orig.data_ptr(), m.weight_u.data_ptr(), m.weight_v.data_ptr())
                                            for m, _, _ in self.specs)
         if key != self._key:
@@ -587,8 +611,9 @@ class SpectralNormBank:
             self._key = key
         pack = torch.empty(self.pack_bytes, dtype=torch.uint8, device=device)
         scratch = torch.empty(self.scratch_floats, dtype=torch.float32, device=device)
-        L.call("sp_sn_forward", ptr(self.table_dev), len(self.specs), self.max_rows, self.max_cols, self.max_pack,
-               ptr(scratch), self.scratch_floats, ptr(pack), 1 if training else 0, sp_dtype(dtype), self.pack_blocks, stream())
+        table, blocks = (self.table_dev, self.pack_blocks) if not skip_pack else self._unpacked_table(skip_pack)
+        L.call("sp_sn_forward", ptr(table), len(self.specs), self.max_rows, self.max_cols, self.max_pack,
+               ptr(scratch), self.scratch_floats, ptr(pack), 1 if training else 0, sp_dtype(dtype), blocks, stream())
         call = self.current = SNCall(self, pack, scratch, dtype)
         weights = [m.weight_orig for m, _, _ in self.specs]
         self.handles = None
@@ -603,13 +628,14 @@ class SpectralNormBank:
             self.handles = hs
         return call
 
-    def begin_pair(self, training: bool, dtype, device, split: int) -> "PairPass":
+    def begin_pair(self, training: bool, dtype, device, split: int, trunk_slots: Optional[frozenset] = None) -> "PairPass":
         """Two consecutive forwards of the bank (two power iterations: the reference's D(real) then D(fake)) for ONE two-group
         pass.  Leaves forward a current (its packing serves the trunk) with `pair` set; use_call() switches between the two for
         the layers that run per group."""
         call_a = self.begin(training, dtype, device)
         handles_a = self.handles
-        call_b = self.begin(training, dtype, device)
+        # trunk_slots: the layers every launch of which takes forward a's packing (+ the per-group scale) - forward b does not pack them
+        call_b = self.begin(training, dtype, device, skip_pack=trunk_slots if CFG.sn_skip_pack else None)
         handles_b = self.handles
         scales = torch.empty(2 * len(self.specs), dtype=torch.float32, device=device)
         L.call("sp_sn_pair_scales", ptr(self.table_dev), len(self.specs), ptr(call_a.scratch), ptr(call_b.scratch), ptr(scales), stream())
