@@ -320,6 +320,16 @@ int sp_bn_apply(const void* x, void* y, int32_t n, int64_t hw, int32_t c, const 
                 int32_t dtype, sp_stream_t stream);
 /* sp_bn_apply fused with the bilinear x2 upsampling (align_corners=True) that follows CBN -> LeakyReLU in a generator block
  * (models.py:296-298): y is [n][2h][2w][c]; every output pixel normalises + activates its four source pixels on the fly. */
+/* The same for a batch of TWO groups - images [0, split) and [split, n) belong to two forwards of the network (round 5: the generator's
+ * two forwards of an iteration in one pass, model_wrapper.py:144-151,165-172) - each group normalised by ITS OWN batch statistics, in
+ * one launch set: mean2 / invstd2 are [2][c]; the running statistics take the two batches one after the other, group `first_group`
+ * first (the forward the reference runs first).  Training mode.  cls: n class indices. */
+int sp_bn_stats_pair(const void* x, int32_t n, int32_t split, int64_t hw, int32_t c, float* partials, float eps, float momentum,
+                     float* running_mean, float* running_var, int32_t first_group, float* mean2, float* invstd2, int32_t dtype,
+                     sp_stream_t stream);
+int sp_bn_apply_pair(const void* x, void* y, int32_t n, int32_t split, int64_t hw, int32_t c, const float* mean2, const float* invstd2,
+                     const float* gamma, const float* beta, const float* emb, const int64_t* cls, int32_t act, int32_t dtype,
+                     sp_stream_t stream);
 int sp_bn_apply_upsample2(const void* x, void* y, int32_t n, int32_t h, int32_t w_, int32_t c, const float* mean,
                           const float* invstd, const float* gamma, const float* beta, const float* emb,
                           const int64_t* cls, int32_t act, int32_t dtype, sp_stream_t stream);

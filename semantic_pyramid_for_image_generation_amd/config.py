@@ -26,6 +26,7 @@ results beyond floating-point summation order.  The kernel library itself reads 
     g_pair                SP_G_PAIR              1        the generator's two forwards of an iteration (D step: no gradient; G step: with) as one two-group pass below 256 x 256 (models.Generator.forward_pair); off while a gradient reducer is active (the G-step forward is what hides D's all-reduce)
     vgg_fc_joint          SP_VGG_FC_JOINT        1        the VGG-16 classifier of a two-batch pass in one launch per layer (up to 64 rows: the weights are streamed once)
     sn_skip_pack          SP_SN_SKIP_PACK        1        the second forward of a two-group pass does not write the packed copies its trunk never reads (ops.SpectralNormBank._unpacked_table)
+    bn_pair               SP_BN_PAIR             1        generator pair pass: a conditional BatchNorm over both groups in one launch set, each group on its own statistics (sp_bn_stats_pair / sp_bn_apply_pair)
     f16_loss_scale        SP_F16_LOSS_SCALE      65536    static loss scale of the fp16 storage mode (ops.set_compute_dtype(torch.float16))
     vgg_fp8               SP_VGG_FP8             0        BASELINE.json config 5's fp8 slice: VGG-16's wide 3x3 layers on the fp8 MFMA in the no-gradient pass (ops.set_vgg_fp8)
     lib_path              SEMPYR_LIB             (in-tree libsempyr.so)
@@ -64,6 +65,7 @@ class Config:
     fuse_tail_grad: bool = True
     vgg_fc_joint: bool = True
     sn_skip_pack: bool = True
+    bn_pair: bool = True
 
     @classmethod
     def from_env(cls) -> "Config":
@@ -77,7 +79,7 @@ class Config:
                    wgrad_side_stream=int(os.environ.get("SP_WGRAD_SIDE_STREAM", "0")), reuse_feature_maps=_flag("SP_REUSE_FEATURE_MAPS", True), vgg_pair=_flag("SP_VGG_PAIR", True),
                    vgg_pool_idx=_flag("SP_VGG_POOL_IDX", True), g_pair=_flag("SP_G_PAIR", True),
                    fuse_tail_grad=_flag("SP_FUSE_TAIL_GRAD", True), vgg_fc_joint=_flag("SP_VGG_FC_JOINT", True),
-                   sn_skip_pack=_flag("SP_SN_SKIP_PACK", True))
+                   sn_skip_pack=_flag("SP_SN_SKIP_PACK", True), bn_pair=_flag("SP_BN_PAIR", True))
 
 
 CFG = Config.from_env()

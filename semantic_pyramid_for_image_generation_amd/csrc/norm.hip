@@ -51,9 +51,13 @@ __device__ __forceinline__ Lay make_lay(int ngroups) {
 }
 
 // part[blockIdx.x][c][0..1] = (sum x, sum x^2) over this block's pixels
+// blockIdx.y = group of a two-group batch (sp_bn_stats_pair): images [0, split) / [split, n) of one tensor, each with its own
+// statistics - pixels_b / part_stride describe the second group (a one-group launch has gridDim.y == 1)
 template <typename T, int V>
-__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, long pixels, int C, float* __restrict__ part) {
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, long pixels, int C, float* __restrict__ part,
+                                                       long pixels_b = 0, long part_stride = 0) {
     __shared__ float red[256 * 2 * V];
+    if (blockIdx.y == 1) { x += pixels * C; part += part_stride; pixels = pixels_b; }
     const int ngroups = C / V;
     const Lay L = make_lay(ngroups);
     for (int cbase = 0; cbase < ngroups; cbase += L.lanes_per_pix) {
@@ -99,10 +103,43 @@ constexpr int BN_EMB_MAXN = 256;         // largest batch of the conditional (cl
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nparts, long count, int C, float eps,
                                                           float momentum, float* __restrict__ running_mean,
                                                           float* __restrict__ running_var, int training,
-                                                          float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+                                                          float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                          int groups = 1, long count_b = 0, long part_stride = 0, int first_group = 0) {
     __shared__ double red[256 * 2];
     const int cl = threadIdx.x % FIN_CL, bl = threadIdx.x / FIN_CL;
     const int c = blockIdx.x * FIN_CL + cl;
+    if (groups == 2) {
+        // two-group batch (sp_bn_stats_pair): both groups' statistics in this launch; the running statistics take the two batches ONE
+        // AFTER THE OTHER, first_group first - the order in which the reference runs the two forwards (training mode only)
+        for (int step = 0; step < 2; ++step) {
+            const int g = step == 0 ? first_group : 1 - first_group;
+            const float2* p2 = reinterpret_cast<const float2*>(part + (long)g * part_stride);
+            const long cnt = g == 0 ? count : count_b;
+            double gs = 0.0, gq = 0.0;
+            if (c < C) {
+#pragma unroll 8
+                for (int b = bl; b < nparts; b += FIN_NL) { const float2 t = p2[(long)b * C + c]; gs += t.x; gq += t.y; }
+            }
+            __syncthreads();
+            red[threadIdx.x * 2] = gs;
+            red[threadIdx.x * 2 + 1] = gq;
+            __syncthreads();
+            if (bl == 0 && c < C) {
+                for (int k = 1; k < FIN_NL; ++k) { gs += red[(k * FIN_CL + cl) * 2]; gq += red[(k * FIN_CL + cl) * 2 + 1]; }
+                const double m = gs / (double)cnt;
+                double var = gq / (double)cnt - m * m;
+                if (var < 0.0) var = 0.0;
+                mean_out[(long)g * C + c] = (float)m;
+                invstd_out[(long)g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+                if (running_mean) {
+                    const double unb = cnt > 1 ? var * (double)cnt / (double)(cnt - 1) : var;
+                    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+                    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+                }
+            }
+        }
+        return;
+    }
     double s = 0.0, q = 0.0;
     if (training && c < C)
     {
@@ -138,8 +175,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 template <typename T, int V>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, long hw, int C,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd, Affine aff,
-                                                       int act) {
+                                                       int act, int split = 0x7fffffff) {
     const int n = blockIdx.y;
+    if (n >= split) { mean += C; invstd += C; }              // second group of a two-group batch: its own statistics ([2][C] arrays)
     const int ngroups = C / V;
     const Lay L = make_lay(ngroups);
     const T* xn = x + (long)n * hw * C;
@@ -596,6 +634,44 @@ extern "C" int sp_bn_apply(const void* x, void* y, int32_t n, int64_t hw, int32_
     if (dtype == SP_F32) hipLaunchKernelGGL((bn_apply_kernel<float, 4>), g, dim3(256), 0, s, (const float*)x, (float*)y, (long)hw, c, mean, invstd, aff, act);
     else if (v == 8) hipLaunchKernelGGL((bn_apply_kernel<bf16, 8>), g, dim3(256), 0, s, (const bf16*)x, (bf16*)y, (long)hw, c, mean, invstd, aff, act);
     else hipLaunchKernelGGL((bn_apply_kernel<bf16, 4>), g, dim3(256), 0, s, (const bf16*)x, (bf16*)y, (long)hw, c, mean, invstd, aff, act);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_bn_stats_pair(const void* x, int32_t n, int32_t split, int64_t hw, int32_t c, float* partials, float eps, float momentum,
+                                float* running_mean, float* running_var, int32_t first_group, float* mean2, float* invstd2,
+                                int32_t dtype, sp_stream_t stream) {
+    SP_CHECK_ARG(x && partials && mean2 && invstd2 && c % 4 == 0 && split > 0 && split < n && hw > 0 && (first_group == 0 || first_group == 1),
+                 "sp_bn_stats_pair: bad args (c=%d, n=%d, split=%d)", c, n, split);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long pix_a = (long)split * hw, pix_b = (long)(n - split) * hw;
+    const int v = (dtype == SP_BF16 && c % 8 == 0) ? 8 : 4;
+    int nparts = stat_blocks(pix_a > pix_b ? pix_a : pix_b, c, v);
+    if (nparts > BN_MAX_PARTS / 2) nparts = BN_MAX_PARTS / 2;         // both groups' partial rows share the caller's 1024 * 2 * c floats
+    const long stride = (long)nparts * 2 * c;
+    const dim3 grid(nparts, 2);
+    if (dtype == SP_F32) hipLaunchKernelGGL((bn_stats_kernel<float, 4>), grid, dim3(256), 0, s, (const float*)x, pix_a, c, partials, pix_b, stride);
+    else if (v == 8) hipLaunchKernelGGL((bn_stats_kernel<bf16, 8>), grid, dim3(256), 0, s, (const bf16*)x, pix_a, c, partials, pix_b, stride);
+    else hipLaunchKernelGGL((bn_stats_kernel<bf16, 4>), grid, dim3(256), 0, s, (const bf16*)x, pix_a, c, partials, pix_b, stride);
+    SP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(sp_div_up(c, FIN_CL)), dim3(256), 0, s, partials, nparts, pix_a, c, eps, momentum,
+                       running_mean, running_var, 1, mean2, invstd2, 2, pix_b, stride, first_group);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_bn_apply_pair(const void* x, void* y, int32_t n, int32_t split, int64_t hw, int32_t c, const float* mean2,
+                                const float* invstd2, const float* gamma, const float* beta, const float* emb, const int64_t* cls,
+                                int32_t act, int32_t dtype, sp_stream_t stream) {
+    SP_CHECK_ARG(x && y && mean2 && invstd2 && c % 4 == 0 && split > 0 && split < n, "sp_bn_apply_pair: bad args");
+    SP_CHECK_ARG(!emb || cls, "sp_bn_apply_pair: conditional mode needs class indices");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    Affine aff{gamma, beta, emb, cls};
+    const int v = (dtype == SP_BF16 && c % 8 == 0) ? 8 : 4;
+    const dim3 g(apply_blocks(hw, c, v, n), n);
+    if (dtype == SP_F32) hipLaunchKernelGGL((bn_apply_kernel<float, 4>), g, dim3(256), 0, s, (const float*)x, (float*)y, (long)hw, c, mean2, invstd2, aff, act, split);
+    else if (v == 8) hipLaunchKernelGGL((bn_apply_kernel<bf16, 8>), g, dim3(256), 0, s, (const bf16*)x, (bf16*)y, (long)hw, c, mean2, invstd2, aff, act, split);
+    else hipLaunchKernelGGL((bn_apply_kernel<bf16, 4>), g, dim3(256), 0, s, (const bf16*)x, (bf16*)y, (long)hw, c, mean2, invstd2, aff, act, split);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }

@@ -187,6 +187,7 @@ class _GeneratorPair:
 
     def __init__(self, bank, call_d, call_g, handles_g, scales, n: int):
         self.bank, self.call_d, self.call_g, self.handles_g, self.scales, self.n = bank, call_d, call_g, handles_g, scales, n
+        self.cls2 = None                       # the class indices of both groups (the same samples twice), made on first use
 
     def as_d(self):
         self.bank.use_call(self.call_d, None)
@@ -207,6 +208,27 @@ class _GeneratorPair:
         self.as_g()
         g = fn(x.g, ops.Dest(out[:n]))
         return _Duo(out, g)
+
+    def batch_norm(self, module: "ConditionalBatchNorm", x: _Duo, cls: torch.Tensor, act: int) -> _Duo:
+        """A conditional BatchNorm (+ activation) over both groups, each normalised by ITS OWN batch statistics, in one launch set
+        (sp_bn_stats_pair / sp_bn_apply_pair): the running statistics take group d's batch first (the forward the reference runs
+        first), then group g's; group g's autograd node is built around its half."""
+        n, a = self.n, x.all
+        c, h, w = a.shape[1], a.shape[2], a.shape[3]
+        bn = module.batch_norm
+        dev, sd = a.device, ops.sp_dtype(a.dtype)
+        if self.cls2 is None:
+            self.cls2 = torch.cat([cls, cls])
+        sums = torch.empty(1024 * 2 * c, dtype=torch.float32, device=dev)
+        stat = torch.empty(4 * c, dtype=torch.float32, device=dev)                 # [mean g | mean d | invstd g | invstd d]
+        mean2, invstd2 = stat[:2 * c], stat[2 * c:]
+        ops.L.call("sp_bn_stats_pair", ops.ptr(a), 2 * n, n, h * w, c, ops.ptr(sums), bn.eps, bn.momentum, ops.ptr(bn.running_mean),
+                   ops.ptr(bn.running_var), 1, ops.ptr(mean2), ops.ptr(invstd2), sd, ops.stream())
+        y = ops.nhwc_empty(2 * n, c, h, w, a.dtype, dev)
+        ops.L.call("sp_bn_apply_pair", ops.ptr(a), ops.ptr(y), 2 * n, n, h * w, c, ops.ptr(mean2), ops.ptr(invstd2), None, None,
+                   ops.ptr(module.embedding.weight), ops.ptr(self.cls2), act, sd, ops.stream())
+        g = module(x.g, cls, act, dest=ops.Dest(y[:n], True, (mean2[:c], invstd2[:c])))
+        return _Duo(y, g)
 
     def conv(self, module, x: _Duo, act: int = ACT_NONE, res1: Optional[_Duo] = None, res2: Optional[_Duo] = None) -> _Duo:
         n = self.n
@@ -326,9 +348,14 @@ class GeneratorResidualBlock(nn.Module):
     def forward_pair(self, x: _Duo, f: _Duo, cls: torch.Tensor, pp: _GeneratorPair) -> _Duo:
         """forward() over the two groups of a generator pair pass: the conditional BatchNorms per group (their statistics belong to one
         forward), everything else once over 2n images.  f: this block's masked-feature mapping of both groups."""
-        h = pp.per_group(lambda t, dest: self.main_block[0](t, cls, ACT_LRELU, dest=dest), x)
-        h = pp.conv(self.main_block[3], pp.upsample2(h))
-        h = pp.per_group(lambda t, dest: self.main_block[4](t, cls, ACT_LRELU, dest=dest), h)
+        if CFG.bn_pair:
+            h = pp.batch_norm(self.main_block[0], x, cls, ACT_LRELU)
+            h = pp.conv(self.main_block[3], pp.upsample2(h))
+            h = pp.batch_norm(self.main_block[4], h, cls, ACT_LRELU)
+        else:
+            h = pp.per_group(lambda t, dest: self.main_block[0](t, cls, ACT_LRELU, dest=dest), x)
+            h = pp.conv(self.main_block[3], pp.upsample2(h))
+            h = pp.per_group(lambda t, dest: self.main_block[4](t, cls, ACT_LRELU, dest=dest), h)
         if _COMMUTE_1X1:
             r = pp.upsample2(pp.conv(self.residual_mapping[1], x))
         else:

@@ -1233,6 +1233,16 @@ class _BatchNormFn(torch.autograd.Function):
         require_gpu(x)
         n, h, w, c = dims(x)
         dev = x.device
+        if dest is not None and dest.filled:
+            # a launch set over a two-group batch has already produced this group's output and statistics (sp_bn_stats_pair /
+            # sp_bn_apply_pair, models._GeneratorPair.batch_norm): only the autograd node is built here
+            if upsample or dest.extra is None:
+                raise L.SempyrError("batch_norm: a filled destination needs its (mean, invstd) and the plain form")
+            mean, invstd = dest.extra
+            y = _dest_tensor(dest, (n, c, h, w), x)
+            ctx.act, ctx.training, ctx.upsample = act, training, upsample
+            ctx.save_for_backward(x, gamma, beta, emb, cls, mean, invstd)
+            return y
         sums = torch.empty(1024 * 2 * c, dtype=torch.float32, device=dev)        # per-block partial sums
         mean = torch.empty(c, dtype=torch.float32, device=dev)
         invstd = torch.empty(c, dtype=torch.float32, device=dev)
