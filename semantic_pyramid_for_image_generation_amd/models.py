@@ -845,6 +845,9 @@ class _VGGPyramidFn(torch.autograd.Function):
         import ctypes
         Lb = ops.L
         dev = img.device
+        # (backward() tests every incoming gradient for None: without this, autograd materialises a zero tensor for each of the seven
+        # non-differentiable features of the second group in every backward pass - seven fill launches per step, round-5 timeline)
+        ctx.set_materialize_grads(False)
         ops.PROBE_NET[0] = "vgg"          # bench.py's launch probe: everything until the return below belongs to the frozen pyramid
         n_grad = img.shape[0]
         n = n_grad + (img_b.shape[0] if img_b is not None else 0)
