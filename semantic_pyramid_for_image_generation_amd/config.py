@@ -23,7 +23,7 @@ results beyond floating-point summation order.  The kernel library itself reads 
     reuse_feature_maps    SP_REUSE_FEATURE_MAPS  1        the generator's masked-feature mappings of the G step derived from the D step's forward (same inputs, same weights, other sigma)
     vgg_pair              SP_VGG_PAIR            1        the VGG-16 pyramid of the NEXT batch's real images rides in the generator step's pass over the fake images (one pass over 2B images; ModelWrapper.train_step(next_images_real=...))
     vgg_pool_idx          SP_VGG_POOL_IDX        1        VGG-16 pass WITH gradient: a stage's last convolution stores the pooled output + 2-bit window positions instead of the unpooled tensor (sp_conv_params.pool_idx)
-    g_pair                SP_G_PAIR              1        the generator's two forwards of an iteration (D step: no gradient; G step: with) as one two-group pass below 256 x 256 (models.Generator.forward_pair); off while a gradient reducer is active (the G-step forward is what hides D's all-reduce)
+    g_pair                SP_G_PAIR              1        the generator's two forwards of an iteration (D step: no gradient; G step: with) as one two-group pass below 256 x 256 (models.Generator.forward_pair)
     vgg_fc_joint          SP_VGG_FC_JOINT        1        the VGG-16 classifier of a two-batch pass in one launch per layer (up to 64 rows: the weights are streamed once)
     sn_skip_pack          SP_SN_SKIP_PACK        1        the second forward of a two-group pass does not write the packed copies its trunk never reads (ops.SpectralNormBank._unpacked_table)
     bn_pair               SP_BN_PAIR             1        generator pair pass: a conditional BatchNorm over both groups in one launch set, each group on its own statistics (sp_bn_stats_pair / sp_bn_apply_pair)

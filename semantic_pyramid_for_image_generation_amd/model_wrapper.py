@@ -183,10 +183,9 @@ class ModelWrapper(object):
 
     # ------------------------------------------------------------------------------------------
     def _g_pair_ok(self) -> bool:
-        """Both generator forwards of the iteration in one pass (config.CFG.g_pair): this package's generator in training mode, and no
-        gradient reducer at work - under data parallelism the generator-step forward is what the discriminator's all-reduce hides
-        behind (distributed.py), and taking it early would expose that transfer."""
-        return (CFG.g_pair and isinstance(self.generator, Generator) and self.generator.training and not self._reducer_active())
+        """Both generator forwards of the iteration in one pass (config.CFG.g_pair): this package's generator in training mode.  (Under
+        data parallelism the discriminator's gradient all-reduce then hides behind _g_features instead of the generator forward.)"""
+        return CFG.g_pair and isinstance(self.generator, Generator) and self.generator.training
 
     def _d_phase(self, images_real, labels, labels_f, masks, noise_d, features_real=None, noise_g=None):
         """model_wrapper.py:136-160: forward passes and backward of the discriminator step (everything but Adam).  features_real: the
@@ -248,28 +247,41 @@ class ModelWrapper(object):
         n, _, h, w = images_fake.shape
         return n * (h // 64) * (w // 64) <= 384
 
-    def _g_rest(self, images_fake, noise_g, labels, masks, features_real, w_rec, w_div, next_images_real=None, features_next_out=None):
-        """model_wrapper.py:174-188: D(fake), the three generator losses, backward (everything but Adam).  next_images_real: the real
-        images of the NEXT iteration - their pyramid (model_wrapper.py:141 of that iteration; the network is frozen) is taken in the
-        same pass as the fake images' (VGG16.forward_pair) and kept in self._vgg_ahead; features_next_out: static tensors to copy it
-        into after the backward pass (captured graphs)."""
-        D, V = self.discriminator, self.vgg16
+    def _g_features(self, images_fake, noise_g, w_div, next_images_real=None):
+        """The part of the generator step that does NOT read the discriminator (model_wrapper.py:179-186): the diversity loss and the
+        frozen VGG-16's pass over the fake images.  train_step runs it BEFORE the discriminator's optimizer step: under data parallelism
+        this pass (1.7 ms at batch 20) - together with the generator forward, where that has not already ridden in the discriminator
+        phase (_g_pair_ok) - is what the discriminator's gradient all-reduce hides behind.  next_images_real: the real images of the NEXT
+        iteration, whose pyramid (model_wrapper.py:141 of that iteration; the network is frozen) is taken in the same pass
+        (VGG16.forward_pair).  Returns (diversity loss, features of the fake images, features of the next real images or None)."""
+        # the weights ride inside this package's loss kernels; a caller's own loss module is weighted the reference's way
+        if isinstance(self.diversity_loss, DiversityLoss):
+            loss_div = self.diversity_loss(images_fake, noise_g, weight=w_div)
+        else:
+            loss_div = w_div * self.diversity_loss(images_fake, noise_g)
+        features_next = None
+        if self._vgg_pair_ok(images_fake, next_images_real):
+            features_fake, features_next = self.vgg16.forward_pair(images_fake, next_images_real)
+        else:
+            features_fake = self.vgg16(images_fake)
+        return loss_div, features_fake, features_next
+
+    def _g_rest(self, images_fake, noise_g, labels, masks, features_real, w_rec, w_div, next_images_real=None, features_next_out=None,
+                ahead=None):
+        """model_wrapper.py:174-188: D(fake), the generator and reconstruction losses, backward (everything but Adam).  ahead: what
+        _g_features has already computed for these fake images (train_step: in front of the discriminator's optimizer step); without
+        it that part runs here.  features_next_out: static tensors to copy the next batch's pyramid into after the backward pass
+        (captured graphs); it is kept in self._vgg_ahead."""
+        D = self.discriminator
         D.zero_grad()
+        if ahead is None:
+            ahead = self._g_features(images_fake, noise_g, w_div, next_images_real)
+        loss_div, features_fake, features_next = ahead
         for p in self._d_params:                               # dead D weight gradients are skipped
             p.requires_grad_(False)
         try:
             prediction_fake = D(images_fake, labels)
             loss_g = self.generator_loss(prediction_fake)
-            # the weights ride inside this package's loss kernels; a caller's own loss module is weighted the reference's way
-            if isinstance(self.diversity_loss, DiversityLoss):
-                loss_div = self.diversity_loss(images_fake, noise_g, weight=w_div)
-            else:
-                loss_div = w_div * self.diversity_loss(images_fake, noise_g)
-            features_next = None
-            if self._vgg_pair_ok(images_fake, next_images_real):
-                features_fake, features_next = V.forward_pair(images_fake, next_images_real)
-            else:
-                features_fake = V(images_fake)
             if isinstance(self.semantic_reconstruction_loss, SemanticReconstructionLoss):
                 loss_rec = self.semantic_reconstruction_loss(features_real, features_fake, masks, weight=w_rec)
             else:
@@ -316,8 +328,9 @@ class ModelWrapper(object):
         images instead of two over B (config.CFG.vgg_pair) - and the next call finds its pyramid computed.  Results do not change:
         the network is frozen and in eval mode.
 
-        Order of work (results identical to the reference's order): D phase; [D gradients -> side stream]; generator forward of
-        the G phase (independent of D); join; Adam(D); rest of the G phase; [G gradients -> side stream]; join; Adam(G)."""
+        Order of work (results identical to the reference's order): D phase (with both generator forwards where _g_pair_ok); [D gradients
+        -> side stream]; what the G phase can do without the discriminator - the generator forward if it is still due, the diversity
+        loss, the VGG-16 pass over the fake images; join; Adam(D); rest of the G phase; [G gradients -> side stream]; join; Adam(G)."""
         # the one-hot labels become class indices ONCE per step (the reference's modules take the argmax in every forward,
         # models.py:151,501: five reductions and a float copy per step; our modules pass indices through)
         # - only for this package's modules: a caller's own module may take the argmax of what it is given (round-4 ADVICE)
@@ -331,11 +344,13 @@ class ModelWrapper(object):
             self._start_reduce("d", self._d_params, eager=True)
         with profiling.range("G forward"):
             images_fake, noise_g = self._g_forward(images_real, labels_f, masks, features_real, noise_g)
+            ahead = self._g_features(images_fake, noise_g, w_div, next_images_real)
         with profiling.range("Adam(D)"):
             self._join_reduce("d")
             self._optimizer_step("d", self.discriminator_optimizer)
         with profiling.range("G rest"):
-            loss_g, loss_rec, loss_div = self._g_rest(images_fake, noise_g, labels, masks, features_real, w_rec, w_div, next_images_real)
+            loss_g, loss_rec, loss_div = self._g_rest(images_fake, noise_g, labels, masks, features_real, w_rec, w_div, next_images_real,
+                                                      ahead=ahead)
             self._start_reduce("g", self._g_params, eager=True)
         with profiling.range("Adam(G)"):
             self._join_reduce("g")
@@ -393,18 +408,17 @@ class ModelWrapper(object):
                 lab_g = cls if isinstance(self.generator, Generator) else st["labels"]
                 feats, l_real, l_fake = self._d_phase(st["images"], lab_d, lab_g, st["masks"], st["noise_d"], st["feats_real"], st["noise_g"])
             st["d_grads"] = [p.grad for p in self._d_params]
-            if self._fake_ahead is not None:
-                # the generator-step forward rode in the discriminator phase's pass: nothing is left for a graph of its own
-                gf = None
+            # second graph: what the generator step can do in front of the discriminator's optimizer step - its forward, unless that rode
+            # in the discriminator phase's pass (Generator.forward_pair), the diversity loss and the VGG-16 pass over the fake images
+            gf = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gf, pool=gd.pool()):
                 fake, _ = self._g_forward(st["images"], lab_g, st["masks"], feats, st["noise_g"])
-            else:
-              gf = torch.cuda.CUDAGraph()
-              with torch.cuda.graph(gf, pool=gd.pool()):
-                fake, _ = self._g_forward(st["images"], lab_g, st["masks"], feats, st["noise_g"])
+                ahead = self._g_features(fake, st["noise_g"], w_div, st.get("images_next"))
+            st["noise_g_early"] = self._g_pair_ok()             # both latents feed the FIRST graph then
             gg = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gg, pool=gd.pool()):
                 l_g, l_rec, l_div = self._g_rest(fake, st["noise_g"], lab_d, st["masks"], feats, w_rec, w_div, st.get("images_next"),
-                                                 st["feats_real"])
+                                                 st["feats_real"], ahead=ahead)
             st["g_grads"] = [p.grad for p in self._g_params]
         finally:
             self._capturing = False
@@ -447,7 +461,7 @@ class ModelWrapper(object):
             st["noise_d"].normal_()
         else:
             st["noise_d"].copy_(noise_d)
-        if st["gf"] is None:                                    # both generator forwards run in the first graph: it needs both draws
+        if st["noise_g_early"]:                                 # both generator forwards run in the first graph: it needs both draws
             if noise_g is None:
                 st["noise_g"].normal_()
             else:
@@ -488,13 +502,13 @@ class ModelWrapper(object):
             for p, g in zip(self._d_params, st["d_grads"]):
                 p.grad = g
             self._start_reduce("d", self._d_params, eager=False)
-        if st["gf"] is not None:
+        if not st["noise_g_early"]:
             if noise_g is None:
                 st["noise_g"].normal_()
             else:
                 st["noise_g"].copy_(noise_g)
-            with profiling.range("G forward"):
-                st["gf"].replay()                               # generator forward: overlaps the D gradient all-reduce
+        with profiling.range("G forward"):
+            st["gf"].replay()                                   # (generator forward,) diversity loss, VGG pass: overlap the D gradient all-reduce
         with profiling.range("Adam(D)"):
             self._join_reduce("d")
             self._optimizer_step("d", self.discriminator_optimizer)

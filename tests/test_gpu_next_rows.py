@@ -241,7 +241,7 @@ class _HalvingReducer:
         pass
 
 
-def test_eager_group_hooks_reduce_every_gradient_exactly_once(monkeypatch):
+def test_eager_group_hooks_reduce_every_gradient_exactly_once():
     """Round-3 ADVICE (medium): on the eager data-parallel path the bank's layer groups hand their flat range to the reducer from
     INSIDE the backward pass.  A gradient that reaches the flat buffer only after .backward() returned (the discriminator head's
     classification bias used to) is then skipped as 'already reduced' - un-averaged on N > 1 ranks - and its late copy races with
@@ -251,9 +251,6 @@ def test_eager_group_hooks_reduce_every_gradient_exactly_once(monkeypatch):
     images, labels, masks = gu.golden_batches(4, 1)[0]
     images, labels, masks = images.cuda(), labels.cuda(), [m.cuda() for m in masks]
     noise = torch.randn(2, 4, 128, generator=torch.Generator().manual_seed(5)).cuda()
-    # (an active reducer keeps the generator-step forward out of the discriminator phase's pass, config.CFG.g_pair: the reducer-less
-    # reference run must launch the same kernels for a bit-for-bit comparison)
-    monkeypatch.setattr(CFG, "g_pair", False)
 
     def run(reducer):
         G, D, V = build(4, 1)
@@ -261,7 +258,7 @@ def test_eager_group_hooks_reduce_every_gradient_exactly_once(monkeypatch):
         mw = sp.ModelWrapper(generator=G, discriminator=D, vgg16=V, training_dataset=None, validation_dataset=None,
                              generator_optimizer=og, discriminator_optimizer=od, save_data_path=None, gradient_reducer=reducer)
         G.train(); D.train()
-        feats, _, _ = mw._d_phase(images, labels, labels.float(), masks, noise[0])
+        feats, _, _ = mw._d_phase(images, labels, labels.float(), masks, noise[0], None, noise[1])     # (both latents: the generator pair pass)
         mw._start_reduce("d", mw._d_params, eager=True)
         dg = {n: p.grad.detach().clone() for n, p in D.named_parameters()}
         fake, z = mw._g_forward(images, labels.float(), masks, feats, noise[1])
@@ -281,7 +278,7 @@ def test_eager_group_hooks_reduce_every_gradient_exactly_once(monkeypatch):
             assert torch.equal(got[n], ref[n] * 0.5), (tag, n)
 
 
-def test_multi_gpu_code_path_in_a_one_rank_rccl_group(monkeypatch):
+def test_multi_gpu_code_path_in_a_one_rank_rccl_group():
     """Row e on one GPU: a real RCCL process group of ONE rank with the reducer kept live (single_rank_passthrough=False), so the
     side stream, the events, the in-place bucketed all-reduce of the flat gradient buffers, the group hooks of the eager
     backward and the three-graph replay all run - the collective itself is the identity, so every result must be bit-identical
@@ -291,7 +288,6 @@ def test_multi_gpu_code_path_in_a_one_rank_rccl_group(monkeypatch):
     ops.set_compute_dtype(torch.float32)
     batches = gu.golden_batches(4, 1)
     noise = torch.randn(4, 4, 128, generator=torch.Generator().manual_seed(2)).cuda()
-    monkeypatch.setattr(CFG, "g_pair", False)         # as above: the same kernels with and without the reducer
 
     def run(reducer, graphed):
         G, D, V = build(4, 1)
