@@ -111,7 +111,9 @@ def test_sn_conv_forward_backward(case, dtype):
 
 # The launches that dominate the benchmark step (bench.py: channel_factor 1, batch 20 per GPU), at their real sizes
 REAL_SHAPE_CASES = [(256, 256, 3, 20, 64, 64), (512, 512, 3, 20, 32, 32), (64, 64, 3, 20, 256, 256), (512, 512, 3, 20, 16, 16),
-                    (128, 128, 3, 20, 128, 128), (512, 512, 3, 20, 8, 8), (768, 768, 3, 20, 4, 4)]
+                    (128, 128, 3, 20, 128, 128), (512, 512, 3, 20, 8, 8), (768, 768, 3, 20, 4, 4),
+                    # the two-group passes' batch of 40 on 8 x 8 maps: 320 tiles of 64 x 64 -> the 128 co x 64 px tile + three K splits (round 5)
+                    (512, 512, 3, 40, 8, 8), (768, 768, 3, 40, 4, 4)]
 
 
 @pytest.mark.parametrize("case", REAL_SHAPE_CASES)
