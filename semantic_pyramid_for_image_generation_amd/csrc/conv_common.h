@@ -189,6 +189,14 @@ __device__ __forceinline__ void conv_epilogue_pool2(const sp_conv_params& p, con
 template <typename T> __device__ __forceinline__ float round_to_storage(float v);
 template <> __device__ __forceinline__ float round_to_storage<float>(float v) { return v; }
 template <> __device__ __forceinline__ float round_to_storage<bf16>(float v) { return bf16_bits_to_f32(f32_to_bf16_bits(v)); }
+// two values at once (one packed conversion instead of two)
+template <typename T> __device__ __forceinline__ void round_pair_to_storage(float& a, float& b);
+template <> __device__ __forceinline__ void round_pair_to_storage<float>(float&, float&) {}
+template <> __device__ __forceinline__ void round_pair_to_storage<bf16>(float& a, float& b) {
+    const uint32_t w = f32x2_to_bf16x2(a, b);
+    a = h16_lo_to_f32(w);
+    b = h16_hi_to_f32(w);
+}
 template <typename T>
 __device__ __forceinline__ void conv_epilogue_pool2_idx(const sp_conv_params& p, const float (&a0)[16], const float (&a1)[16],
                                                         const float (&b0)[16], const float (&b1)[16], int lane, long ppix_row, int pcol0,
@@ -207,8 +215,9 @@ __device__ __forceinline__ void conv_epilogue_pool2_idx(const sp_conv_params& p,
     unsigned idx = 0;
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-        const float ra0 = round_to_storage<T>(a0[c] + bias[c]), ra1 = round_to_storage<T>(a1[c] + bias[c]);
-        const float rb0 = round_to_storage<T>(b0[c] + bias[c]), rb1 = round_to_storage<T>(b1[c] + bias[c]);
+        float ra0 = a0[c] + bias[c], ra1 = a1[c] + bias[c], rb0 = b0[c] + bias[c], rb1 = b1[c] + bias[c];
+        round_pair_to_storage<T>(ra0, ra1);
+        round_pair_to_storage<T>(rb0, rb1);
         const bool fa = ra1 > ra0, fb = rb1 > rb0;                            // the vertical maximum sits in row 1 (only if strictly greater)
         const float ma = fa ? ra1 : ra0, mb = fb ? rb1 : rb0;
         const float mine = odd ? mb : ma;
