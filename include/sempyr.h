@@ -330,6 +330,9 @@ int sp_bn_stats_pair(const void* x, int32_t n, int32_t split, int64_t hw, int32_
 int sp_bn_apply_pair(const void* x, void* y, int32_t n, int32_t split, int64_t hw, int32_t c, const float* mean2, const float* invstd2,
                      const float* gamma, const float* beta, const float* emb, const int64_t* cls, int32_t act, int32_t dtype,
                      sp_stream_t stream);
+int sp_bn_apply_upsample2_pair(const void* x, void* y, int32_t n, int32_t split, int32_t h, int32_t w_, int32_t c, const float* mean2,
+                               const float* invstd2, const float* gamma, const float* beta, const float* emb, const int64_t* cls,
+                               int32_t act, int32_t dtype, sp_stream_t stream);   /* sp_bn_apply_upsample2 on a batch of two groups */
 int sp_bn_apply_upsample2(const void* x, void* y, int32_t n, int32_t h, int32_t w_, int32_t c, const float* mean,
                           const float* invstd, const float* gamma, const float* beta, const float* emb,
                           const int64_t* cls, int32_t act, int32_t dtype, sp_stream_t stream);

@@ -212,7 +212,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 template <typename T, int V>
 __global__ __launch_bounds__(256) void bn_apply_upsample2_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C,
                                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                                 Affine aff, int act) {
+                                                                 Affine aff, int act, int split = 0x7fffffff) {
+    // (split: samples >= split take the second row of [2][C] statistics - a batch of two groups, sp_bn_apply_upsample2_pair)
     // grid (column slabs, N * OH): a block owns (part of) ONE output row, so the sample, the two source rows and the row weight
     // are block-uniform, and a thread keeps one channel group: its parameters are loaded once (16-byte loads), the loop body is
     // four loads -> fma / activation -> blend -> store without any integer division (the flat-index form decoded (n, oh, ow, c)
@@ -235,7 +236,8 @@ __global__ __launch_bounds__(256) void bn_apply_upsample2_kernel(const T* __rest
         {
             float mu[V], is[V];
             aff.template getv<V>(n, c, C, a, b);
-            ldv<V>(mean + c, mu); ldv<V>(invstd + c, is);
+            const int go = n >= split ? C : 0;
+            ldv<V>(mean + go + c, mu); ldv<V>(invstd + go + c, is);
 #pragma unroll
             for (int r = 0; r < V; ++r) { a[r] *= is[r]; b[r] -= mu[r] * a[r]; }
         }
@@ -691,6 +693,25 @@ extern "C" int sp_bn_apply_upsample2(const void* x, void* y, int32_t n, int32_t 
     if (dtype == SP_F32) hipLaunchKernelGGL((bn_apply_upsample2_kernel<float, 4>), g, dim3(256), 0, s, (const float*)x, (float*)y, n, h, w_, c, mean, invstd, aff, act);
     else if (v == 8) hipLaunchKernelGGL((bn_apply_upsample2_kernel<bf16, 8>), g, dim3(256), 0, s, (const bf16*)x, (bf16*)y, n, h, w_, c, mean, invstd, aff, act);
     else hipLaunchKernelGGL((bn_apply_upsample2_kernel<bf16, 4>), g, dim3(256), 0, s, (const bf16*)x, (bf16*)y, n, h, w_, c, mean, invstd, aff, act);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_bn_apply_upsample2_pair(const void* x, void* y, int32_t n, int32_t split, int32_t h, int32_t w_, int32_t c, const float* mean2,
+                                          const float* invstd2, const float* gamma, const float* beta, const float* emb,
+                                          const int64_t* cls, int32_t act, int32_t dtype, sp_stream_t stream) {
+    SP_CHECK_ARG(x && y && mean2 && invstd2 && c % 4 == 0 && n > 0 && h > 0 && w_ > 0 && split > 0 && split < n, "sp_bn_apply_upsample2_pair: bad args");
+    SP_CHECK_ARG(!emb || cls, "sp_bn_apply_upsample2_pair: conditional mode needs class indices");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    Affine aff{gamma, beta, emb, cls};
+    const int v = (dtype == SP_BF16 && c % 8 == 0) ? 8 : 4;
+    const int groups = c / v, lanes = groups < 256 ? groups : 256, pix_par = 256 / lanes;
+    int bx = ((2 * w_ + 2) / 4 + 1 + pix_par - 1) / pix_par;
+    if (bx < 1) bx = 1;
+    const dim3 g(bx, (long)n * 2 * h < 65535 ? n * 2 * h : 65535);
+    if (dtype == SP_F32) hipLaunchKernelGGL((bn_apply_upsample2_kernel<float, 4>), g, dim3(256), 0, s, (const float*)x, (float*)y, n, h, w_, c, mean2, invstd2, aff, act, split);
+    else if (v == 8) hipLaunchKernelGGL((bn_apply_upsample2_kernel<bf16, 8>), g, dim3(256), 0, s, (const bf16*)x, (bf16*)y, n, h, w_, c, mean2, invstd2, aff, act, split);
+    else hipLaunchKernelGGL((bn_apply_upsample2_kernel<bf16, 4>), g, dim3(256), 0, s, (const bf16*)x, (bf16*)y, n, h, w_, c, mean2, invstd2, aff, act, split);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }

@@ -209,7 +209,7 @@ class _GeneratorPair:
         g = fn(x.g, ops.Dest(out[:n]))
         return _Duo(out, g)
 
-    def batch_norm(self, module: "ConditionalBatchNorm", x: _Duo, cls: torch.Tensor, act: int) -> _Duo:
+    def batch_norm(self, module: "ConditionalBatchNorm", x: _Duo, cls: torch.Tensor, act: int, upsample: bool = False) -> _Duo:
         """A conditional BatchNorm (+ activation) over both groups, each normalised by ITS OWN batch statistics, in one launch set
         (sp_bn_stats_pair / sp_bn_apply_pair): the running statistics take group d's batch first (the forward the reference runs
         first), then group g's; group g's autograd node is built around its half."""
@@ -224,10 +224,17 @@ class _GeneratorPair:
         mean2, invstd2 = stat[:2 * c], stat[2 * c:]
         ops.L.call("sp_bn_stats_pair", ops.ptr(a), 2 * n, n, h * w, c, ops.ptr(sums), bn.eps, bn.momentum, ops.ptr(bn.running_mean),
                    ops.ptr(bn.running_var), 1, ops.ptr(mean2), ops.ptr(invstd2), sd, ops.stream())
-        y = ops.nhwc_empty(2 * n, c, h, w, a.dtype, dev)
-        ops.L.call("sp_bn_apply_pair", ops.ptr(a), ops.ptr(y), 2 * n, n, h * w, c, ops.ptr(mean2), ops.ptr(invstd2), None, None,
-                   ops.ptr(module.embedding.weight), ops.ptr(self.cls2), act, sd, ops.stream())
-        g = module(x.g, cls, act, dest=ops.Dest(y[:n], True, (mean2[:c], invstd2[:c])))
+        if upsample:
+            # ... and the bilinear x2 that follows in the same pass (sp_bn_apply_upsample2_pair): the normalised low-resolution tensor is
+            # neither written nor read back (re-measured in round 5 with the row-per-block bilinear kernels: +0.25 % on two forwards)
+            y = ops.nhwc_empty(2 * n, c, 2 * h, 2 * w, a.dtype, dev)
+            ops.L.call("sp_bn_apply_upsample2_pair", ops.ptr(a), ops.ptr(y), 2 * n, n, h, w, c, ops.ptr(mean2), ops.ptr(invstd2), None, None,
+                       ops.ptr(module.embedding.weight), ops.ptr(self.cls2), act, sd, ops.stream())
+        else:
+            y = ops.nhwc_empty(2 * n, c, h, w, a.dtype, dev)
+            ops.L.call("sp_bn_apply_pair", ops.ptr(a), ops.ptr(y), 2 * n, n, h * w, c, ops.ptr(mean2), ops.ptr(invstd2), None, None,
+                       ops.ptr(module.embedding.weight), ops.ptr(self.cls2), act, sd, ops.stream())
+        g = module(x.g, cls, act, upsample, dest=ops.Dest(y[:n], True, (mean2[:c], invstd2[:c])))
         return _Duo(y, g)
 
     def conv(self, module, x: _Duo, act: int = ACT_NONE, res1: Optional[_Duo] = None, res2: Optional[_Duo] = None) -> _Duo:
@@ -349,8 +356,10 @@ class GeneratorResidualBlock(nn.Module):
         """forward() over the two groups of a generator pair pass: the conditional BatchNorms per group (their statistics belong to one
         forward), everything else once over 2n images.  f: this block's masked-feature mapping of both groups."""
         if CFG.bn_pair:
-            h = pp.batch_norm(self.main_block[0], x, cls, ACT_LRELU)
-            h = pp.conv(self.main_block[3], pp.upsample2(h))
+            if CFG.bn_pair_upsample:
+                h = pp.conv(self.main_block[3], pp.batch_norm(self.main_block[0], x, cls, ACT_LRELU, upsample=True))
+            else:
+                h = pp.conv(self.main_block[3], pp.upsample2(pp.batch_norm(self.main_block[0], x, cls, ACT_LRELU)))
             h = pp.batch_norm(self.main_block[4], h, cls, ACT_LRELU)
         else:
             h = pp.per_group(lambda t, dest: self.main_block[0](t, cls, ACT_LRELU, dest=dest), x)

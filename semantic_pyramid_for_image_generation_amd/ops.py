@@ -1236,10 +1236,10 @@ class _BatchNormFn(torch.autograd.Function):
         if dest is not None and dest.filled:
             # a launch set over a two-group batch has already produced this group's output and statistics (sp_bn_stats_pair /
             # sp_bn_apply_pair, models._GeneratorPair.batch_norm): only the autograd node is built here
-            if upsample or dest.extra is None:
-                raise L.SempyrError("batch_norm: a filled destination needs its (mean, invstd) and the plain form")
+            if upsample == "before" or dest.extra is None:
+                raise L.SempyrError("batch_norm: a filled destination needs its (mean, invstd) and the plain or the up-sampling form")
             mean, invstd = dest.extra
-            y = _dest_tensor(dest, (n, c, h, w), x)
+            y = _dest_tensor(dest, (n, c, 2 * h, 2 * w) if upsample else (n, c, h, w), x)
             ctx.act, ctx.training, ctx.upsample = act, training, upsample
             ctx.save_for_backward(x, gamma, beta, emb, cls, mean, invstd)
             return y
@@ -1320,8 +1320,8 @@ class _BatchNormFn(torch.autograd.Function):
 
 
 def batch_norm(x, gamma, beta, emb, cls, running_mean, running_var, momentum, eps, training, act, upsample=False, dest: Optional[Dest] = None):
-    if dest is not None and upsample:
-        raise L.SempyrError("batch_norm: a destination slice goes with the plain (not up-sampling) form")
+    if dest is not None and upsample and not dest.filled:
+        raise L.SempyrError("batch_norm: an unfilled destination slice goes with the plain (not up-sampling) form")
     return _BatchNormFn.apply(x, gamma, beta, emb, cls, running_mean, running_var, momentum, eps, training, act, upsample, dest)
 
 
