@@ -4,7 +4,7 @@ import ctypes, torch
 from semantic_pyramid_for_image_generation_amd import ops, _lib as L
 lib = L.lib(); dt = torch.bfloat16; B = 20
 names = ["frag reads issue", "vmcnt wait", "barrier after L", "mfma segment", "barrier after M", "epilogue+init", "dma issue", "lgkm wait"]
-for cin, cout, hw in [(128, 128, 128), (256, 256, 64), (64, 128, 128)]:
+for cin, cout, hw in [(64, 64, 256), (128, 64, 256), (128, 128, 128), (256, 256, 64), (64, 128, 128)]:
     x = ops.nhwc_empty(B, cin, hw, hw, dt, 'cuda'); x.normal_()
     w = (torch.randn(cout * 9 * cin, device='cuda') * 0.05).to(dt)
     bias = torch.randn(cout, device='cuda'); y = ops.nhwc_empty(B, cout, hw, hw, dt, 'cuda')
@@ -21,11 +21,11 @@ for cin, cout, hw in [(128, 128, 128), (256, 256, 64), (64, 128, 128)]:
     for half, sl in (("waves 0-3", slice(0, 4)), ("waves 4-7", slice(4, 8))):
         m = t[:, sl, :].mean(dim=(0, 1)); tot = m.sum().item()
         print("%d->%d @%d %s: total %.0f cycles | " % (cin, cout, hw, half, tot) + " | ".join("%s %.1f%%" % (n, 100 * v / tot) for n, v in zip(names, m.tolist())))
-    e = t16[:, :, 8:12].mean(dim=(0, 1)).tolist(); items = B * (hw // 8) * (hw // 32) * ((cout + 127) // 128) / 256
+    e = t16[:, :, 8:12].mean(dim=(0, 1)).tolist(); th = 16 if cout <= 64 else 8; items = B * (hw // th) * (hw // 32) * ((cout + 127) // 128) / 256
     print("   per item: acc init %.0f | item-end setup %.0f | fragments %.0f | next coordinates %.0f cycles" % tuple(v / items for v in e))
-    stages = (B * (hw // 8) * (hw // 32) * ((cout + 127) // 128) / 256) * ((cin + 31) // 32) * 3
+    stages = items * ((cin + 31) // 32) * 3
     if (int(sys.argv[1]) if len(sys.argv) > 1 else 5) & 512:
-        mid = (B * (hw // 8) * (hw // 32) * ((cout + 127) // 128) / 256) * max((cin + 31) // 32 - 2, 0) * 3
+        mid = items * max((cin + 31) // 32 - 2, 0) * 3
         m = t.mean(dim=(0, 1)).tolist()
         print("   MID chunks only (%d stages): per stage " % mid + " | ".join("%s %.0f" % (n, v / max(mid, 1)) for n, v in zip(names, m)))
     print("   stages per block %.1f -> cycles per stage %.0f" % (stages, t.sum(dim=2).mean().item() / stages))

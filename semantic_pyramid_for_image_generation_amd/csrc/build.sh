@@ -11,7 +11,7 @@ set -e
 cd "$(dirname "$0")"
 OUT=../libsempyr.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result -Wno-pass-failed ${SP_EXTRA_FLAGS}"     # SP_EXTRA_FLAGS: experiment builds (e.g. -DSP_NT_STORES)
-SRCS="conv_igemm conv_pp fp8 conv_wgrad conv_wgrad_rows conv_wgrad_1x1 spectral_norm linear eltwise norm resample attention losses optim"
+SRCS="conv_igemm conv_pp conv_ppw fp8 conv_wgrad conv_wgrad_rows conv_wgrad_1x1 spectral_norm linear eltwise norm resample attention losses optim"
 mkdir -p build
 python3 ../../tools/gen_h16.py build > /dev/null
 keep=" api.o dispatch_h16.o"

@@ -1599,6 +1599,19 @@ int dispatch(const sp_conv_params& p, hipStream_t s) {
             const long rt = (bt + 255) / 256, rh = (2 * bt + 255) / 256;
             int th = (tall_ok && 19 * rt < 10 * rh) ? 16 : 8;
             if (pp_mode == 8 || (pp_mode == 16 && tall_ok)) th = pp_mode;
+            // 16-row patches: conv_ppw.hip (64 co x 4 rows per wave, 0.25 LDS reads per MFMA under the ping-pong schedule) where its
+            // epilogue covers the launch.  One of its items takes 1.72 - 2.04 x the time of an 8-row item (the longer K, the better: its
+            // 128-value epilogue amortises; scratch/test_ppw.py, profiles/README.md) - it wins where the round count says so, and
+            // everywhere the lockstep tall<2,16> kernel used to (8 - 15 % faster on the same tiles).  SP_TUNE_CONV_PPW: 0 off, 2 forced
+            const int ppw_mode = sp_tune(SP_TUNE_CONV_PPW, 1);
+            if (tall_ok && ppw_mode && pp_mode == 1) {
+                const int kch = (p.cin_p + 31) / 32;
+                const long ratio = kch >= 12 ? 172 : kch >= 6 ? 185 : kch >= 3 ? 194 : 204;
+                if (ppw_mode == 2 || ratio * rt < 100 * rh) {
+                    const int rc = sp_conv_ppw_launch(p, s);
+                    if (rc != 1) return rc;
+                }
+            }
             if (!(pp_mode == 1 && th == 16)) {             // (the 16-row form is reached only when forced: see conv_pp.hip)
                 const int rc = sp_conv_pp_launch(p, th, s);
                 if (rc != 1) return rc;

@@ -731,8 +731,11 @@ int sp_conv_pp_launch(const sp_conv_params& p, int th, hipStream_t s) {
         if (th == 8 && p.cout > 64) return launch_pp<bf16, 2, 1, false, true, false, 2, false, true>(p, prio, s);
         return 1;
     }
-    if (th == 16 && p.cout <= 64)                          // 64 co x 16x32 px
+    if (th == 16 && p.cout <= 64) {                        // 64 co x 16x32 px
+        if ((prio & 4) && fast && p.workspace != nullptr && p.workspace_bytes >= 256L * 8 * 16 * 4)
+            return launch_pp<bf16, 1, 1, true, true, true>(p, prio, s);       // (TIMING build, see below)
         return fast ? launch_pp<bf16, 1, 1, false, true, true>(p, prio, s) : launch_pp<bf16, 1, 1>(p, prio, s);
+    }
     if (th != 8 || p.cout <= 64) return 1;
     // the TIMING build writes 256 x 8 x 16 floats of stamps into the caller's workspace: only with a workspace that holds them
     if ((prio & 4) && p.workspace != nullptr && p.workspace_bytes >= 256L * 8 * 16 * 4)
