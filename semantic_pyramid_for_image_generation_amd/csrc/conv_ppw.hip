@@ -23,8 +23,8 @@
 // wait of every wave that requested a piece of it (the wait sits at the end of L_B, the reads of the next stage in L_A two
 // segments later; with the requests in L_B a stage's own pieces are the only ones that may still fly at its wait); a ring slot / halo buffer is re-requested >= 1 barrier after its last read.
 //
-// Scope: 16-bit storage, Cout > 64, h % 16 == 0, w % 32 == 0, the FAST epilogue's promises (Cout % 16 == 0, ldy % 8 == 0, no pooling,
-// no tanh).  Everything else stays on conv_pp.hip / the tall kernel (conv_igemm.hip decides).
+// Scope: 16-bit storage, Cout > 64, h % 16 == 0, w % 32 == 0, whole 16-channel groups (Cout % 16 == 0, ldy % 8 == 0), no tanh, no
+// recorded pooling positions, no fused tail.  Everything else stays on conv_pp.hip / the tall kernel (conv_igemm.hip decides).
 #include "conv_common.h"
 
 namespace {
@@ -47,7 +47,7 @@ struct PWGeom {
     static constexpr int LDS = OFF_DUMMY + 1024;
 };
 
-template <typename T, bool TIMING = false, bool DMA_LB = true>
+template <typename T, bool TIMING = false, bool DMA_LB = true, bool POOL = false>
 __global__ __launch_bounds__(512) void conv3x3_ppw_kernel(sp_conv_params p, int cotiles, int total, int prio) {
     static_assert(sizeof(T) == 2, "16-bit storage");
     using G = PWGeom<T>;
@@ -333,6 +333,26 @@ __global__ __launch_bounds__(512) void conv3x3_ppw_kernel(sp_conv_params p, int 
 #pragma unroll
                     for (int j = 0; j < NFR; ++j) acc[i][j] *= 0.25f;
             }
+            if constexpr (POOL) {                                        // (own instantiation: the plain form keeps its register allocation)
+                // 2x2 average / maximum pooling in the epilogue (the discriminator's second convolutions, the VGG stages): fragments
+                // j0 .. j0 + 3 = rows (2k, 2k + 1) x column halves; bias / scale / residuals / activation at the pooled resolution
+                // (conv_common.h: conv_epilogue_pool2, the helper of the other 3x3 kernels - bit-identical outputs)
+                if (wide) {
+                    static_for<NFR / 4>([&](auto gq) {
+                        constexpr int j0 = decltype(gq)::value * 4;
+                        const long prow = ((long)n * (H >> 1) + ((ty0 + RW * wpx + (j0 >> 1)) >> 1)) * (W >> 1);
+                        float av[16], bv[16];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                av[i * 4 + r] = pool2_combine(acc[i][j0][r], acc[i][j0 + 2][r], p.pool2 == 2);
+                                bv[i * 4 + r] = pool2_combine(acc[i][j0 + 1][r], acc[i][j0 + 3][r], p.pool2 == 2);
+                            }
+                        conv_epilogue_pool2<T>(p, av, bv, lane, prow, tx0 >> 1, co_b, !bias_in_acc);
+                    });
+                }
+            } else {
             if (p.img_scale != nullptr) {                                // two-group batch: the item's image picks the scale (uniform)
                 const float sc = p.img_scale[n >= p.img_split ? 1 : 0];
 #pragma unroll
@@ -411,6 +431,7 @@ __global__ __launch_bounds__(512) void conv3x3_ppw_kernel(sp_conv_params p, int 
                     });
                 });
             }
+            }
             kc = 0;
             cur = nxt;
             nxt = advance(nxt);
@@ -431,12 +452,12 @@ __global__ __launch_bounds__(512) void conv3x3_ppw_kernel(sp_conv_params p, int 
     }
 }
 
-template <typename T, bool TIMING, bool DMA_LB = true>
+template <typename T, bool TIMING, bool DMA_LB = true, bool POOL = false>
 int launch_ppw(const sp_conv_params& p, int prio, hipStream_t s) {
     using G = PWGeom<T>;
     static_assert(G::LDS <= 163840, "LDS budget");
     static bool attr_set = false;
-    auto kern = conv3x3_ppw_kernel<T, TIMING, DMA_LB>;
+    auto kern = conv3x3_ppw_kernel<T, TIMING, DMA_LB, POOL>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
         if (e != hipSuccess) { sp_set_error("hipFuncSetAttribute(LDS=%d) failed: %s", G::LDS, hipGetErrorString(e)); return SP_ERR_LAUNCH; }
@@ -460,8 +481,9 @@ int sp_conv_ppw_launch(const sp_conv_params& p, hipStream_t s) {
     if (p.dtype != SP_BF16 || p.ksize != 3 || p.cout <= 64) return 1;
     if (p.h % 16 != 0 || p.w_ % 32 != 0) return 1;
     if ((long)p.n * p.h * p.w_ * p.cin_p * 2 >= (1L << 30) || (long)p.cout * 9 * p.cin_p * 2 >= (1L << 30)) return 1;
-    if (p.pool2 != 0 || (p.cout & 15) != 0 || (p.ldy & 7) != 0 || p.act == SP_ACT_TANH || p.tail_w != nullptr || p.pool_idx != nullptr || p.y == nullptr) return 1;
+    if ((p.cout & 15) != 0 || (p.ldy & 7) != 0 || p.act == SP_ACT_TANH || p.tail_w != nullptr || p.pool_idx != nullptr || p.y == nullptr) return 1;
     const int prio = sp_tune(SP_TUNE_CONV_PP_PRIO, 1);
+    if (p.pool2) return launch_ppw<bf16, false, true, true>(p, prio, s);
     if ((prio & 4) && p.workspace != nullptr && p.workspace_bytes >= 256L * 8 * 16 * 4) return launch_ppw<bf16, true>(p, prio, s);
     if (prio & 64) return launch_ppw<bf16, false, false>(p, prio, s);      // (A/B: the requests in L_A, one behind every three reads)
     return launch_ppw<bf16, false>(p, prio, s);

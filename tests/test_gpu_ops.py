@@ -252,12 +252,15 @@ def test_conv3x3_pingpong_epilogue_variants_bf16(case):
         assert torch.equal(y0, y1), (case, rep, int((y0 != y1).sum()))
 
 
-PPW_CASES = [  # (n, cin, cout, h, w, act, residuals, mask, input-upsampled, bias, two groups)
-    (2, 128, 128, 64, 64, 1, 0, False, False, True, False), (3, 64, 128, 32, 64, 0, 2, False, False, True, False),
-    (3, 136, 192, 32, 32, 2, 0, False, False, True, False), (2, 128, 256, 64, 64, 0, 0, True, False, False, False),
-    (2, 256, 128, 64, 64, 0, 0, True, True, False, False), (5, 32, 144, 16, 32, 1, 1, False, False, True, False),
-    (4, 72, 128, 32, 32, 0, 0, False, False, True, True), (20, 512, 512, 32, 32, 1, 1, True, False, True, True),
-    (40, 64, 128, 32, 32, 0, 0, False, False, False, False),
+PPW_CASES = [  # (n, cin, cout, h, w, act, residuals, mask, input-upsampled, bias, two groups, pool2)
+    (2, 128, 128, 64, 64, 1, 0, False, False, True, False, 0), (3, 64, 128, 32, 64, 0, 2, False, False, True, False, 0),
+    (3, 136, 192, 32, 32, 2, 0, False, False, True, False, 0), (2, 128, 256, 64, 64, 0, 0, True, False, False, False, 0),
+    (2, 256, 128, 64, 64, 0, 0, True, True, False, False, 0), (5, 32, 144, 16, 32, 1, 1, False, False, True, False, 0),
+    (4, 72, 128, 32, 32, 0, 0, False, False, True, True, 0), (20, 512, 512, 32, 32, 1, 1, True, False, True, True, 0),
+    (40, 64, 128, 32, 32, 0, 0, False, False, False, False, 0),
+    # pooled epilogues: average (+ residual at the pooled resolution, two groups: the discriminator's pair pass), maximum, a partial channel tile
+    (4, 128, 128, 64, 64, 0, 1, False, False, True, True, 1), (3, 64, 256, 32, 64, 2, 0, False, False, True, False, 2),
+    (2, 96, 208, 32, 32, 0, 2, False, False, True, False, 1),
 ]
 
 
@@ -265,17 +268,19 @@ PPW_CASES = [  # (n, cin, cout, h, w, act, residuals, mask, input-upsampled, bia
 def test_conv3x3_pingpong_four_row_waves_bf16(case):
     """conv_ppw.hip (128 co x 16 x 32 px per block, 64 co x 4 rows per wave, stages cut into two column halves, three-slot weight
     ring) FORCED onto every launch its epilogue covers (SP_TUNE_CONV_PPW = 2) - bias, LeakyReLU / ReLU, residuals, the
-    activation-gradient mask, the pooled-gradient input, the per-group accumulator scales of a two-group batch, partial channel tiles
+    activation-gradient mask, the pooled-gradient input, 2x2 average / max pooling in the epilogue, the per-group accumulator scales of a
+    two-group batch, partial channel tiles
     and partial K chunks, one and many items per block: (a) against fp32 arithmetic on the same bf16 operands, (b) BIT-IDENTICAL to
     the round-2 kernels (SP_TUNE_CONV_PP = 0), three launches each into a dirty output."""
-    n, cin, cout, h, w_, act, res, mask, up, bias, groups = case
+    n, cin, cout, h, w_, act, res, mask, up, bias, groups, pool2 = case
     dt = torch.bfloat16
     g = torch.Generator(device="cuda").manual_seed(11)
+    ho, wo = (h // 2, w_ // 2) if pool2 else (h, w_)
     hin, win = (h // 2, w_ // 2) if up else (h, w_)
     x = ops.nhwc_empty(n, cin, hin, win, dt, "cuda").normal_(generator=g)
     w = (torch.randn(cout, 3, 3, cin, device="cuda", generator=g) * 0.05).to(dt)
     b = torch.randn(cout, device="cuda", generator=g) if bias else None
-    mk = lambda: ops.nhwc_empty(n, cout, h, w_, dt, "cuda").normal_(generator=g)
+    mk = lambda: ops.nhwc_empty(n, cout, ho, wo, dt, "cuda").normal_(generator=g)
     r1 = mk() if res >= 1 else None
     r2 = mk() if res >= 2 else None
     ms = mk() if mask else None
@@ -283,7 +288,7 @@ def test_conv3x3_pingpong_four_row_waves_bf16(case):
     scales = torch.tensor([1.0, 0.8125], device="cuda") if groups else None
 
     def launch(y):
-        ops._conv_launch(x, w.data_ptr(), b, y, r1, r2, ms, 0.2, n, h, w_, cin, cout, cout, 3, act, dt, 0, up,
+        ops._conv_launch(x, w.data_ptr(), b, y, r1, r2, ms, 0.2, n, h, w_, cin, cout, cout, 3, act, dt, pool2, up,
                          img_scale=scales.data_ptr() if groups else 0, img_split=split if groups else 0)
 
     xin = x.float()
@@ -292,6 +297,8 @@ def test_conv3x3_pingpong_four_row_waves_bf16(case):
     ref = F.conv2d(xin, w.float().permute(0, 3, 1, 2), None, padding=1)
     if groups:
         ref[split:] *= 0.8125
+    if pool2:
+        ref = F.avg_pool2d(ref, 2) if pool2 == 1 else F.max_pool2d(ref, 2)
     if b is not None:
         ref = ref + b.view(1, -1, 1, 1)
     if ms is not None:
@@ -303,14 +310,14 @@ def test_conv3x3_pingpong_four_row_waves_bf16(case):
     ref = {0: lambda t: t, 1: lambda t: F.leaky_relu(t, 0.2), 2: F.relu}[act](ref)
     ops.set_tuning(21, 0)
     try:
-        y0 = ops.nhwc_empty(n, cout, h, w_, dt, "cuda").fill_(3.0)
+        y0 = ops.nhwc_empty(n, cout, ho, wo, dt, "cuda").fill_(3.0)
         launch(y0)
     finally:
         ops.set_tuning(21, -1)
     ops.set_tuning(L.TUNE_KEYS["SP_CONV_PPW"], 2)
     try:
         for rep in range(3):
-            y1 = ops.nhwc_empty(n, cout, h, w_, dt, "cuda").fill_(-7.0)
+            y1 = ops.nhwc_empty(n, cout, ho, wo, dt, "cuda").fill_(-7.0)
             launch(y1)
             assert "conv3x3_ppw" in L.lib().sp_last_route().decode(), L.lib().sp_last_route().decode()
             if rep == 0:
