@@ -77,6 +77,7 @@ int sp_version(void);
  *                            2 = 128 co x 64 px, 3 = 64 co x 128 px; default: 0, or 2 where 64 x 64 tiles make 1 - 2 rounds of the chip and K is long
  *   SP_TUNE_CONV_PPW         16-bit 3x3 layers with Cout > 64 on 16 x 32-pixel patches: the ping-pong kernel with 64 co x 4 rows per wave
  *                            (conv_ppw.hip) where the round count favours 16-row items; 0 = off (tall<2,16> / the 8-row form), 2 = wherever eligible
+ *   SP_TUNE_LINEAR_KS        K range per block of the split-K MFMA linear kernel: 1024 / 512 / 256 / 128 (default: the widest that yields 256 blocks)
  *   SP_TUNE_BN_ITERS         pixels per thread of the elementwise BatchNorm passes (grid sizing; default 2)
  *   SP_TUNE_CONV_PP_PRIO     bit 0: s_setprio 1 around every MFMA segment of the ping-pong kernel (default 1); bit 1: static priority 1
  *                            for the second-dispatched half of the block */
@@ -84,7 +85,7 @@ enum { SP_TUNE_CONV_TALL = 0, SP_TUNE_IGEMM_DMA = 1, SP_TUNE_WGRAD_ROWS = 2, SP_
        SP_TUNE_SPLITK_TARGET = 4, SP_TUNE_SPLITK_MINSTEPS = 5, SP_TUNE_CONV1X1_DIRECT = 6, SP_TUNE_CONV_SHORT = 7,
        SP_TUNE_WGRAD9_BLOCKS = 8, SP_TUNE_WGRAD_BLOCKS = 9, SP_TUNE_WGRAD_MINSTEPS = 10, SP_TUNE_WGRAD_SMALL_M = 11,
        SP_TUNE_WGRAD_K1_TILE64 = 12, SP_TUNE_WGRAD_ROWS_THIN = 13, SP_TUNE_WGRAD_ROWS_BLOCKS = 14, SP_TUNE_WGRAD_ROWS_SLABS = 15,
-       SP_TUNE_CONV_STAGGER = 16, SP_TUNE_CONV1X1_SPLITK = 17, SP_TUNE_WGRAD1X1 = 18, SP_TUNE_CONV_CIN8 = 19, SP_TUNE_CONV_THINCO = 20, SP_TUNE_CONV_PP = 21, SP_TUNE_CONV_PP_PRIO = 22, SP_TUNE_WGRAD_PP = 23, SP_TUNE_BN_ITERS = 24, SP_TUNE_IGEMM_TILE = 25, SP_TUNE_CONV_PPW = 26, SP_TUNE_COUNT = 27 };
+       SP_TUNE_CONV_STAGGER = 16, SP_TUNE_CONV1X1_SPLITK = 17, SP_TUNE_WGRAD1X1 = 18, SP_TUNE_CONV_CIN8 = 19, SP_TUNE_CONV_THINCO = 20, SP_TUNE_CONV_PP = 21, SP_TUNE_CONV_PP_PRIO = 22, SP_TUNE_WGRAD_PP = 23, SP_TUNE_BN_ITERS = 24, SP_TUNE_IGEMM_TILE = 25, SP_TUNE_CONV_PPW = 26, SP_TUNE_LINEAR_KS = 27, SP_TUNE_COUNT = 28 };
 int sp_set_tuning(int32_t key, int32_t value);
 const char* sp_last_error_string(void);
 /* Name of the kernel (route) the last sp_conv2d_igemm / sp_conv2d_wgrad* call of THIS thread launched ("" before the first one):

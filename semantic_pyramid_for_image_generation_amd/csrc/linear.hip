@@ -3,6 +3,8 @@
 // with the transposed packing it is also the input-gradient pass.  One wave owns NR output features
 // and streams their packed weight rows with 16-byte loads; the activation chunk (B x 512) is staged
 // once per block in LDS as fp32, so rows of x may have any pitch/alignment (K = 365 occurs).
+#include <type_traits>
+#include <utility>
 #include "common.h"
 
 namespace {
@@ -132,6 +134,11 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const T* __restrict__
 // layers: 8 splits x 32 row tiles = 256 blocks instead of 128)
 
 // the layer's epilogue, for launches whose single K-split finishes the layer itself (y != nullptr: no slab, no finalize pass)
+template <int... I, typename F>
+__device__ __forceinline__ void lin_static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void lin_static_for(F&& f) { lin_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
 struct LinTail { const float* bias; const bf16* res; bf16* y; int ldy, act; };
 
 // NB = 16-row batch fragments per block: 2 (up to 32 rows) or 4 (up to 64 - round 5: the two-batch VGG-16 pass hands its 40 / 64 rows
@@ -139,36 +146,16 @@ struct LinTail { const float* bias; const bf16* res; bf16* y; int ldy, act; };
 template <int LM_KS, int NB = 2>
 __global__ __launch_bounds__(256) void linear_mfma_kernel(const bf16* __restrict__ x, int ldx, const bf16* __restrict__ wp, int kp,
                                                           float* __restrict__ acc_out, int B, int K, int N, LinTail tail) {
-    constexpr int LM_PITCH = LM_KS * 2 + 16;
+    // the x tile is staged XS columns at a time (two phases for a 1024-wide K range): [16 * NB][XS] in LDS stays at 33 / 66 KB, so two
+    // blocks share a CU and one streams while the other stages, multiplies or stores its slab
+    constexpr int XS = LM_KS < 512 ? LM_KS : 512;
+    constexpr int LM_PITCH = XS * 2 + 16;
     extern __shared__ __attribute__((aligned(16))) char xs_raw[];     // [16 * NB][LM_PITCH bytes]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * 128 + wave * 32;
     const int k0 = blockIdx.y * LM_KS;
     const int klen = min(LM_KS, kp - k0);                            // multiple of 8 (kp is)
-    // stage x[0..16 NB)[k0..k0+klen) (zero padded)
-    const bool vec = ((ldx & 7) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-    for (int e = tid; e < 16 * NB * (LM_KS / 8); e += 256) {
-        const int b = e / (LM_KS / 8), kc = (e - b * (LM_KS / 8)) * 8;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (b < B && kc < klen) {
-            if (vec && k0 + kc + 8 <= K) {
-                v = *reinterpret_cast<const uint4*>(x + (long)b * ldx + k0 + kc);
-            } else {
-                uint16_t t[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) t[q] = (k0 + kc + q < K) ? x[(long)b * ldx + k0 + kc + q].v : (uint16_t)0;
-                v = make_uint4(t[0] | (t[1] << 16), t[2] | (t[3] << 16), t[4] | (t[5] << 16), t[6] | (t[7] << 16));
-            }
-        }
-        *reinterpret_cast<uint4*>(xs_raw + b * LM_PITCH + kc * 2) = v;
-    }
-    __syncthreads();
     const int frow = lane & 15, g = lane >> 4;
-    f32x4_t acc[2][NB];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NB; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const bf16* wrow[2];
     bool wok[2];
 #pragma unroll
@@ -177,38 +164,101 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const bf16* __restrict
         wok[i] = n < N;
         wrow[i] = wp + (long)(wok[i] ? n : 0) * kp + k0 + g * 8;
     }
-    const int nkk = klen / 32;          // full 32-wide steps
-    constexpr int U = 8;
-    for (int kk0 = 0; kk0 < (klen + 31) / 32; kk0 += U) {
-        uint4 a[2][U];
+    // The weights are the traffic (a block streams 128 rows x LM_KS once; the x tile is re-read from L2 by every block): their loads run
+    // LA groups of U k-steps ahead of the MFMAs through a ring of LA + 1 register sets, the first LA groups are requested right behind
+    // the loads of the x tile and before it is staged (round 5: the single-buffered loop had a block's 64 KB in flight, then nothing
+    // while it multiplied; FC1 of the VGG-16 classifier streamed at 1.7 TB/s).  Every load is UNCONDITIONAL: under a per-lane
+    // condition hipcc wrapped each one in an exec branch and followed some with `s_waitcnt vmcnt(0)` + a register copy.  A lane
+    // whose k-chunk lies past the K range re-reads the range's first chunk of its own row instead - its x counterpart is zero
+    // padding, and a non-finite weight there belongs to the same row's sum anyway; rows past N read row 0 and are never stored.
+    constexpr int U = 4, LA = 3, NBUF = LA + 1;
+    constexpr int NG = LM_KS / 32 / U;                                // groups of a full K range
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    uint4 a[NBUF][2][U];
+    auto load_group = [&](uint4 (&dst)[2][U], int q) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int kk = kk0 + u;
+            const int kk = q * U + u;
             const bool k_ok = kk * 32 + g * 8 < klen;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (k_ok && wok[i]) v = *reinterpret_cast<const uint4*>(wrow[i] + kk * 32);
-                a[i][u] = v;
+                const bf16* src = k_ok ? wrow[i] + kk * 32 : wrow[i] - g * 8;
+                const u32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(src));     // streamed once: FC1's 205 MB need not sweep the L2
+                dst[i][u] = make_uint4(t.x, t.y, t.z, t.w);
             }
         }
+    };
+    // x[0..16 NB)[k0 + phase * XS ..) (zero padded): loads into registers first, the LDS writes once they have landed
+    const bool vec = ((ldx & 7) == 0) && ((K & 7) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);     // whole 16-byte chunks only
+    constexpr int XCH = 16 * NB * (XS / 8) / 256;                     // 16-byte chunks per thread and phase
+    static_assert(XCH * 256 == 16 * NB * (XS / 8), "x tile: whole chunks per thread");
+    uint4 xv[XCH];
+    auto x_issue = [&](int ph) {
+#pragma unroll
+        for (int c = 0; c < XCH; ++c) {
+            const int e = c * 256 + tid;
+            const int b = e / (XS / 8), kl = (e - b * (XS / 8)) * 8, kc = ph * XS + kl;
+            const bool ok = b < B && kc < klen && k0 + kc + 8 <= K;
+            const u32x4_t t = *reinterpret_cast<const u32x4_t*>(x + (ok ? (long)b * ldx + k0 + kc : 0L));
+            xv[c] = ok ? make_uint4(t.x, t.y, t.z, t.w) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto x_commit = [&](int ph) {
+#pragma unroll
+        for (int c = 0; c < XCH; ++c) {
+            const int e = c * 256 + tid;
+            const int b = e / (XS / 8), kl = (e - b * (XS / 8)) * 8, kc = ph * XS + kl;
+            *reinterpret_cast<uint4*>(xs_raw + b * LM_PITCH + kl * 2) = xv[c];
+        }
+    };
+    auto x_stage_slow = [&](int ph) {                                 // unaligned rows (ldx % 8 != 0) or K % 8 != 0: element loads
+        for (int e = tid; e < 16 * NB * (XS / 8); e += 256) {
+            const int b = e / (XS / 8), kl = (e - b * (XS / 8)) * 8, kc = ph * XS + kl;
+            uint16_t t[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] = (b < B && kc < klen && k0 + kc + q < K) ? x[(long)b * ldx + k0 + kc + q].v : (uint16_t)0;
+            *reinterpret_cast<uint4*>(xs_raw + b * LM_PITCH + kl * 2) = make_uint4(t[0] | (t[1] << 16), t[2] | (t[3] << 16), t[4] | (t[5] << 16), t[6] | (t[7] << 16));
+        }
+    };
+    if (vec) x_issue(0);
+    lin_static_for<(LA < NG ? LA : NG)>([&](auto qc) { load_group(a[decltype(qc)::value], decltype(qc)::value); });
+    if (vec) x_commit(0); else x_stage_slow(0);
+    __syncthreads();
+    f32x4_t acc[2][NB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    auto mma_group = [&](const uint4 (&src)[2][U], int q) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int kk = kk0 + u;
-            if (kk * 32 >= klen) break;
+            const int kk = q * U + u;
             uint4 bx[NB];
 #pragma unroll
             for (int j = 0; j < NB; ++j)
-                bx[j] = *reinterpret_cast<const uint4*>(xs_raw + (j * 16 + frow) * LM_PITCH + (kk * 32 + g * 8) * 2);
+                bx[j] = *reinterpret_cast<const uint4*>(xs_raw + (j * 16 + frow) * LM_PITCH + ((kk * 32) % XS + g * 8) * 2);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < NB; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[i][u]), __builtin_bit_cast(bf16x8_t, bx[j]),
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, src[i][u]), __builtin_bit_cast(bf16x8_t, bx[j]),
                                                                         acc[i][j], 0, 0, 0);
         }
-    }
-    (void)nkk;
+    };
+    constexpr int GPP = XS / 32 / U;                                  // groups per staging phase
+    lin_static_for<NG>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        if constexpr (q > 0 && q % GPP == 0) {                        // next phase of the x tile (every wave is done reading the previous one)
+            if (vec) x_issue(q / GPP);
+            if constexpr (q + LA < NG) load_group(a[(q + LA) % NBUF], q + LA);
+            __syncthreads();
+            if (vec) x_commit(q / GPP); else x_stage_slow(q / GPP);
+            __syncthreads();
+        } else {
+            if constexpr (q + LA < NG) load_group(a[(q + LA) % NBUF], q + LA);
+        }
+        mma_group(a[q % NBUF], q);
+    });
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -253,14 +303,27 @@ __global__ void linear_finalize_kernel(const float* __restrict__ acc, int nsplit
 // Rows of up to 1024 values take ONE split (K per block = the smallest of 128 / 512 / 1024 that covers the row): the block applies
 // bias / residual / activation from its registers and the finalize launch - ~5 us of queue time, as much as the layer itself - is gone
 // (the latent / linear-block 128 -> 128 layers, D's 768 -> 128, the 365 -> 128 class mapping and their input gradients).
-static inline int linear_ks(int kp) { return kp > 8192 ? 1024 : (kp >= 2048 ? 512 : (kp > 1024 ? 128 : (kp > 512 ? 1024 : (kp > 128 ? 512 : 128)))); }
+// Larger matrices - K range per block of the split-K MFMA kernel: the widest of 1024 / 512 / 256 / 128 that still yields LIN_MIN_BLOCKS = 256 blocks (measured per shape, scratch/bench_linear.py; blocks
+// keep the weight stream going while a neighbour stages its x tile or stores its slab; a wider range means fewer fp32 slabs - every
+// split writes and the finalize pass re-reads batch x n floats); SP_TUNE_LINEAR_KS forces a width
+constexpr int LIN_MIN_BLOCKS = 256;
+static inline int linear_ks(int kp, int n) {
+    const int forced = sp_tune(SP_TUNE_LINEAR_KS, 0);
+    if (forced == 1024 || forced == 512 || forced == 256 || forced == 128) return forced;
+    const long nt = (n + 127) / 128;
+    // small layers (the rule above): one split, no finalize launch - the widths this kernel is instantiated for that cover the row
+    if ((long)n * kp <= (1L << 18) && kp <= 1024) return kp > 512 ? 1024 : (kp > 256 ? 512 : (kp > 128 ? 256 : 128));
+    for (int ks = 1024; ks > 128; ks >>= 1)
+        if (nt * ((kp + ks - 1) / ks) >= LIN_MIN_BLOCKS) return ks;
+    return 128;
+}
 static inline bool linear_use_mfma(int dtype, int batch, int k, int n) { return dtype == SP_BF16 && batch <= 64 && (long)k * n >= (1L << 12); }
 
 template <int KS, int NB>
 static void launch_linear_mfma_nb(dim3 grid, hipStream_t s, const bf16* x, int ldx, const bf16* w, int kp, float* scratch, int batch, int k, int n,
                                   const LinTail& tail) {
     static bool a = false;
-    const int lds = 16 * NB * (KS * 2 + 16);
+    const int lds = 16 * NB * ((KS < 512 ? KS : 512) * 2 + 16);
     if (!a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_mfma_kernel<KS, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); a = true; }
     hipLaunchKernelGGL((linear_mfma_kernel<KS, NB>), grid, dim3(256), lds, s, x, ldx, w, kp, scratch, batch, k, n, tail);
 }
@@ -323,12 +386,13 @@ extern "C" int sp_linear_fwd_ws(const void* x, int32_t ldx, const void* w_packed
     SP_CHECK_ARG(x && w_packed && y, "sp_linear_fwd_ws: null pointer");
     SP_CHECK_ARG(batch > 0 && k > 0 && n > 0 && kp >= k && kp % 8 == 0 && ldx >= k && ldy >= n, "sp_linear_fwd_ws: bad dims");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int ks = linear_ks(kp);
+    const int ks = linear_ks(kp, n);
     const int nsplit = sp_div_up(kp, ks);
     dim3 grid(sp_div_up(n, 128), nsplit);
     const LinTail tail{bias, (const bf16*)res, nsplit == 1 ? (bf16*)y : nullptr, ldy, act};
     if (ks == 1024) launch_linear_mfma<1024>(grid, s, (const bf16*)x, ldx, (const bf16*)w_packed, kp, scratch, batch, k, n, tail);
     else if (ks == 512) launch_linear_mfma<512>(grid, s, (const bf16*)x, ldx, (const bf16*)w_packed, kp, scratch, batch, k, n, tail);
+    else if (ks == 256) launch_linear_mfma<256>(grid, s, (const bf16*)x, ldx, (const bf16*)w_packed, kp, scratch, batch, k, n, tail);
     else launch_linear_mfma<128>(grid, s, (const bf16*)x, ldx, (const bf16*)w_packed, kp, scratch, batch, k, n, tail);
     SP_LAUNCH_CHECK();
     if (nsplit == 1) return SP_OK;
@@ -343,6 +407,6 @@ extern "C" int sp_linear_workspace(int32_t batch, int32_t k, int32_t n, int32_t 
     SP_CHECK_ARG(floats_out && batch > 0 && k > 0 && n > 0, "sp_linear_workspace: bad args");
     const int kp = (k + 7) / 8 * 8;
     const bool big = linear_use_mfma(dtype, batch, k, n);
-    *floats_out = big ? (int64_t)sp_div_up(kp, linear_ks(kp)) * batch * n : 0;
+    *floats_out = big ? (int64_t)sp_div_up(kp, linear_ks(kp, n)) * batch * n : 0;      // (ask again after changing SP_TUNE_LINEAR_KS)
     return SP_OK;
 }

@@ -728,6 +728,7 @@ def set_tuning(key: int, value: int) -> None:
     L.call("sp_set_tuning", key, value)
     _CONV_WS_CACHE.clear()
     _WS_CACHE.clear()
+    _LIN_WS_CACHE.clear()
 
 
 def conv_launch(x, w_ptr: int, bias, y, res1, res2, mask_src, slope: float, n, h, w, cin_p, cout, ldy, ksize, act,
