@@ -169,6 +169,36 @@ def test_ping_pong_kernels_random_shapes(seed):
     assert not fails, fails
 
 
+@pytest.mark.parametrize("dt,seed", [(torch.bfloat16, 0), (torch.bfloat16, 5), (torch.float16, 1)])
+def test_four_row_wave_kernel_random_shapes(dt, seed):
+    """conv_ppw.hip forced onto every launch it covers (SP_TUNE_CONV_PPW = 2): random channel counts (partial K chunks: 72, 136, 264;
+    partial channel tiles: 80 ... 320), 16-row multiples, every epilogue operand, pooled epilogues, pooled-gradient inputs, one to
+    many items per block - both 16-bit storage types, each case launched twice into dirty outputs, against fp32 arithmetic."""
+    _seed(seed)
+    ops.set_compute_dtype(dt)
+    fails, hits = [], 0
+    ops.set_tuning(L.TUNE_KEYS["SP_CONV_PPW"], 2)
+    try:
+        for _ in range(36):
+            cout = random.choice([128, 256, 136, 192, 80, 320, 512])
+            cin = random.choice([32, 64, 72, 128, 136, 256, 264])
+            n, h, w = random.randint(1, 9), 16 * random.randint(1, 4), 32 * random.randint(1, 3)
+            pool2 = random.choice([0, 0, 0, 1, 2]) if cout % 16 == 0 else 0
+            act = random.choice([0, 1, 2] if pool2 == 0 else [0, 2])
+            res = random.choice([0, 0, 1, 2]) if pool2 != 2 else 0
+            mask = random.random() < 0.25 and pool2 == 0
+            bias = random.random() < 0.8
+            up = pool2 == 0 and random.random() < 0.2
+            e = _conv_case(dt, n, cin, cout, 3, h, w, act, res, mask, pool2, bias, up)
+            hits += "conv3x3_ppw" in L.lib().sp_last_route().decode()
+            if e > (8e-3 if dt == torch.bfloat16 else 2e-3):
+                fails.append((n, cin, cout, h, w, act, res, mask, pool2, bias, up, e))
+    finally:
+        ops.set_tuning(L.TUNE_KEYS["SP_CONV_PPW"], -1)
+    assert not fails, fails
+    assert hits >= 24, hits                      # (Cout % 16 != 0 cases fall to the other kernels)
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-4), (torch.bfloat16, 3e-2)])
 def test_batch_norm_and_bilinear_random_shapes(dtype, tol):
     """scratch/stress_norm_resample.py: BatchNorm plain / conditional / fused with the bilinear pass, bilinear x2, vs autograd."""
