@@ -1604,13 +1604,14 @@ int dispatch(const sp_conv_params& p, hipStream_t s) {
             // 128-value epilogue amortises; scratch/test_ppw.py, profiles/README.md) - it wins where the round count says so, and
             // everywhere the lockstep tall<2,16> kernel used to (8 - 15 % faster on the same tiles).  SP_TUNE_CONV_PPW: 0 off, 2 forced
             const int ppw_mode = sp_tune(SP_TUNE_CONV_PPW, 1);
-            if (tall_ok && ppw_mode && pp_mode == 1) {
+            if (tall_ok && ppw_mode && pp_mode == 1 && sp_conv_ppw_covers(p)) {
                 const int kch = (p.cin_p + 31) / 32;
                 const long ratio = kch >= 12 ? 172 : kch >= 6 ? 185 : kch >= 3 ? 194 : 204;
                 if (ppw_mode == 2 || ratio * rt < 100 * rh) {
                     const int rc = sp_conv_ppw_launch(p, s);
                     if (rc != 1) return rc;
                 }
+                th = 8;             // where the four-row form loses on rounds, the 8-row ping-pong form beats the lockstep 16-row kernel too
             }
             if (!(pp_mode == 1 && th == 16)) {             // (the 16-row form is reached only when forced: see conv_pp.hip)
                 const int rc = sp_conv_pp_launch(p, th, s);

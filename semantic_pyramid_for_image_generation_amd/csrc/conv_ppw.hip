@@ -477,11 +477,15 @@ int launch_ppw(const sp_conv_params& p, int prio, hipStream_t s) {
 
 // conv_igemm.hip's dispatch(): 16-bit 3x3 layers with more than 64 output channels on 16 x 32-pixel patches whose epilogue is the
 // FAST one.  Returns 1 if the shape is not covered (the caller then keeps its own kernel).
+int sp_conv_ppw_covers(const sp_conv_params& p) {
+    if (p.dtype != SP_BF16 || p.ksize != 3 || p.cout <= 64) return 0;
+    if (p.h % 16 != 0 || p.w_ % 32 != 0) return 0;
+    if ((long)p.n * p.h * p.w_ * p.cin_p * 2 >= (1L << 30) || (long)p.cout * 9 * p.cin_p * 2 >= (1L << 30)) return 0;
+    return !((p.cout & 15) != 0 || (p.ldy & 7) != 0 || p.act == SP_ACT_TANH || p.tail_w != nullptr || p.pool_idx != nullptr || p.y == nullptr);
+}
+
 int sp_conv_ppw_launch(const sp_conv_params& p, hipStream_t s) {
-    if (p.dtype != SP_BF16 || p.ksize != 3 || p.cout <= 64) return 1;
-    if (p.h % 16 != 0 || p.w_ % 32 != 0) return 1;
-    if ((long)p.n * p.h * p.w_ * p.cin_p * 2 >= (1L << 30) || (long)p.cout * 9 * p.cin_p * 2 >= (1L << 30)) return 1;
-    if ((p.cout & 15) != 0 || (p.ldy & 7) != 0 || p.act == SP_ACT_TANH || p.tail_w != nullptr || p.pool_idx != nullptr || p.y == nullptr) return 1;
+    if (!sp_conv_ppw_covers(p)) return 1;
     const int prio = sp_tune(SP_TUNE_CONV_PP_PRIO, 1);
     if (p.pool2) return launch_ppw<bf16, false, true, true>(p, prio, s);
     if ((prio & 4) && p.workspace != nullptr && p.workspace_bytes >= 256L * 8 * 16 * 4) return launch_ppw<bf16, true>(p, prio, s);
