@@ -208,6 +208,19 @@ int sp_conv2d_wgrad_workspace(int32_t n, int32_t h, int32_t w_, int32_t cin_p, i
 int sp_conv2d_wgrad_accum_pair(const void* x, const void* dy, float* dw_a, float* dbias_a, float* dw_b, float* dbias_b, float* workspace,
                                int64_t workspace_floats, int32_t n, int32_t split, int32_t h, int32_t w_, int32_t cin_p, int32_t cout,
                                int32_t ld_dy, int32_t ksize, int32_t dy_pooled, int32_t dtype, sp_stream_t stream);
+/* Deferred slab reductions.  The streaming weight-gradient kernels of the 1x1 and 8-channel 3x3 layers split the pixels over blocks,
+ * leave one partial tile per split in the workspace and a second, tiny launch adds the partial tiles to dW in a fixed order.  Nothing
+ * reads dW before the end of a backward pass (model_wrapper.py:160,188: the optimizer step), so a caller may collect those launches:
+ *   sp_wgrad_reduce_defer(1)        from now on sp_conv2d_wgrad_accum* QUEUE that reduction instead of launching it (a layer whose dW
+ *                                    is already queued keeps its own launch);
+ *   sp_wgrad_reduce_flush(1, s)     ONE launch per 48 queued reductions on stream s (descriptors by value: capturable), the same
+ *                                    arithmetic in the same order - bit-identical to the separate launches;
+ *   sp_wgrad_reduce_flush(0, s)     drops the queue (a pass that was abandoned); sp_wgrad_reduce_pending() = its length;
+ *   sp_wgrad_reduce_defer(0)        back to immediate reductions (what is queued stays queued until the flush).
+ * The caller keeps every workspace alive until the flush and flushes on the stream the weight-gradient launches ran on. */
+int sp_wgrad_reduce_defer(int32_t on);
+int sp_wgrad_reduce_flush(int32_t run, sp_stream_t stream);
+int sp_wgrad_reduce_pending(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Skinny linear layers: y = act(x W^T + bias + res), batch rows of any pitch, weights packed [n][kp]

@@ -28,6 +28,7 @@ results beyond floating-point summation order.  The kernel library itself reads 
     sn_skip_pack          SP_SN_SKIP_PACK        1        the second forward of a two-group pass does not write the packed copies its trunk never reads (ops.SpectralNormBank._unpacked_table)
     bn_pair               SP_BN_PAIR             1        generator pair pass: a conditional BatchNorm over both groups in one launch set, each group on its own statistics (sp_bn_stats_pair / sp_bn_apply_pair)
     bn_pair_upsample      SP_BN_PAIR_UPSAMPLE    1        ... and with the bilinear x2 behind a block's first BatchNorm in the same pass (sp_bn_apply_upsample2_pair)
+    defer_wgrad_reduce    SP_DEFER_WGRAD_REDUCE  1        the slab reductions of the streaming weight-gradient launches of a backward pass in ONE launch at its end (sp_wgrad_reduce_defer / _flush)
     f16_loss_scale        SP_F16_LOSS_SCALE      65536    static loss scale of the fp16 storage mode (ops.set_compute_dtype(torch.float16))
     vgg_fp8               SP_VGG_FP8             0        BASELINE.json config 5's fp8 slice: VGG-16's wide 3x3 layers on the fp8 MFMA in the no-gradient pass (ops.set_vgg_fp8)
     lib_path              SEMPYR_LIB             (in-tree libsempyr.so)
@@ -68,6 +69,7 @@ class Config:
     sn_skip_pack: bool = True
     bn_pair: bool = True
     bn_pair_upsample: bool = True
+    defer_wgrad_reduce: bool = True
 
     @classmethod
     def from_env(cls) -> "Config":
@@ -82,7 +84,7 @@ class Config:
                    vgg_pool_idx=_flag("SP_VGG_POOL_IDX", True), g_pair=_flag("SP_G_PAIR", True),
                    fuse_tail_grad=_flag("SP_FUSE_TAIL_GRAD", True), vgg_fc_joint=_flag("SP_VGG_FC_JOINT", True),
                    sn_skip_pack=_flag("SP_SN_SKIP_PACK", True), bn_pair=_flag("SP_BN_PAIR", True),
-                   bn_pair_upsample=_flag("SP_BN_PAIR_UPSAMPLE", True))
+                   bn_pair_upsample=_flag("SP_BN_PAIR_UPSAMPLE", True), defer_wgrad_reduce=_flag("SP_DEFER_WGRAD_REDUCE", True))
 
 
 CFG = Config.from_env()

@@ -14,7 +14,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unuse
 SRCS="conv_igemm conv_pp conv_ppw fp8 conv_wgrad conv_wgrad_rows conv_wgrad_1x1 spectral_norm linear eltwise norm resample attention losses optim"
 mkdir -p build
 python3 ../../tools/gen_h16.py build > /dev/null
-keep=" api.o dispatch_h16.o"
+keep=" api.o dispatch_h16.o reduce_queue.o"
 for f in $SRCS; do keep="$keep $f.o $f.h16.o"; done
 for o in build/*.o; do
   [ -e "$o" ] || continue
@@ -34,7 +34,8 @@ for f in $SRCS; do
 done
 for p in "${pids[@]}"; do wait $p; done
 hipcc $FLAGS -c api.cpp -o build/api.o
+if stale build/reduce_queue.o reduce_queue.hip; then hipcc $FLAGS -c reduce_queue.hip -o build/reduce_queue.o; fi     # fp32 only: one compilation
 hipcc $FLAGS -c build/dispatch_h16.cpp -o build/dispatch_h16.o
-OBJS="build/api.o build/dispatch_h16.o"; for f in $SRCS; do OBJS="$OBJS build/$f.o build/$f.h16.o"; done
+OBJS="build/api.o build/dispatch_h16.o build/reduce_queue.o"; for f in $SRCS; do OBJS="$OBJS build/$f.o build/$f.h16.o"; done
 hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $OUT
 echo "built $(realpath $OUT)"

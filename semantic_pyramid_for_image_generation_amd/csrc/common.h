@@ -177,6 +177,8 @@ static inline bool sp_deterministic(int dtype) { return sp_g_tune[SP_TUNE_DETERM
 int sp_conv_pp_launch(const sp_conv_params& p, int th, hipStream_t s);
 int sp_conv_ppw_launch(const sp_conv_params& p, hipStream_t s);      // conv_ppw.hip: 128 co x 16 x 32 px, 64 co x 4 rows per wave
 int sp_conv_ppw_covers(const sp_conv_params& p);                    // ... whether it takes the launch at all (shape, epilogue)
+// reduce_queue.hip (compiled once, shared by both flavours): true = the slab reduction was queued for sp_wgrad_reduce_flush
+bool spq_push_reduce(const float* slabs, int nsplit, long n_dw, float* dw, const float* bias_slabs, int bias_ld, int cout, float* dbias);
 // conv_wgrad_rows.hip: SP_OK after launching, 1 if the shape is not covered
 int sp_wgrad_rows_launch(const void* x, const void* dy, float* dw, float* dbias, int n, int h, int w, int cin, int cout,
                          int ld_dy, float* ws, long ws_floats, int dy_up2, hipStream_t s);

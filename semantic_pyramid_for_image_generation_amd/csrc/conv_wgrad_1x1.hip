@@ -409,6 +409,8 @@ static void w1_reduce_groups(const W1Args& a, int nsplit, int kb, float* dw_a, f
     const long cols = a.n_dw / 4 + (a.bias_slabs != nullptr ? a.bias_ld / 4 : 0);
     for (int g = 0; g < 2; ++g) {
         const int k0 = g ? kb : 0, k1 = g ? nsplit : kb;
+        if (spq_push_reduce(a.slabs + (long)k0 * a.n_dw, k1 - k0, a.n_dw, g ? dw_b : dw_a, a.bias_slabs != nullptr ? a.bias_slabs + (long)k0 * a.bias_ld : nullptr,
+                            a.bias_ld, cout, g ? dbias_b : dbias_a)) continue;          // queued (reduce_queue.hip)
         hipLaunchKernelGGL(wgrad1x1_reduce_kernel, dim3((unsigned)((cols + 15) / 16)), dim3(256), 0, s, a.slabs + (long)k0 * a.n_dw, k1 - k0, a.n_dw,
                            g ? dw_b : dw_a, a.bias_slabs != nullptr ? a.bias_slabs + (long)k0 * a.bias_ld : nullptr, a.bias_ld, cout, g ? dbias_b : dbias_a);
     }
@@ -469,7 +471,7 @@ static int w1_launch_impl(const void* x, const void* dy, float* dw, float* dbias
         SP_LAUNCH_CHECK();
         return SP_OK;
     }
-    if (p.nsplit > 1) {
+    if (p.nsplit > 1 && !spq_push_reduce(a.slabs, p.nsplit, a.n_dw, dw, a.bias_slabs, a.bias_ld, cout, dbias)) {
         const long cols = a.n_dw / 4 + (a.bias_slabs != nullptr ? a.bias_ld / 4 : 0);
         hipLaunchKernelGGL(wgrad1x1_reduce_kernel, dim3((unsigned)((cols + 15) / 16)), dim3(256), 0, s, a.slabs, p.nsplit, a.n_dw, dw, a.bias_slabs,
                            a.bias_ld, cout, dbias);
@@ -561,7 +563,7 @@ static int c8_launch_impl(const void* x, const void* dy, float* dw, float* dbias
         SP_LAUNCH_CHECK();
         return SP_OK;
     }
-    if (p.nsplit > 1) {
+    if (p.nsplit > 1 && !spq_push_reduce(a.slabs, p.nsplit, a.n_dw, dw, a.bias_slabs, a.bias_ld, cout, dbias)) {
         const long cols = a.n_dw / 4 + (a.bias_slabs != nullptr ? a.bias_ld / 4 : 0);
         hipLaunchKernelGGL(wgrad1x1_reduce_kernel, dim3((unsigned)((cols + 15) / 16)), dim3(256), 0, s, a.slabs, p.nsplit, a.n_dw, dw, a.bias_slabs,
                            a.bias_ld, cout, dbias);

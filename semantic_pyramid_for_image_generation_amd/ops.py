@@ -327,6 +327,7 @@ class _SNBankFn(torch.autograd.Function):
             return (None,) * (n + 2)
         if CFG.wgrad_side_stream:
             join_wgrad_stream(call.arena.device)          # weight-gradient launches that ran on the side stream wrote the arena
+        flush_wgrad_reduce()                              # ... and the queued slab reductions of the pass add their sums to it now
         table = ctypes.c_void_p(bank.bwd_table_dev.data_ptr() + lo * ctypes.sizeof(L.SpSnBwdLayer))
         dots = torch.empty(n * 512, dtype=torch.float32, device=call.arena.device)     # per-block partial <dW, W> sums
         start, stop = bank.group_range[g]
@@ -825,6 +826,34 @@ def wgrad_workspace_floats(n, h, w, cin_p, cout, ksize, dtype) -> int:
 
 _WGRAD_STREAMS = {}
 
+# Deferred slab reductions (include/sempyr.h: sp_wgrad_reduce_defer / _flush; CFG.defer_wgrad_reduce).  The 1x1 / 8-channel streaming
+# weight-gradient launches of a backward pass queue their reduce kernels - 31 launches of ~5 us per training step - and the bank's
+# backward node (which runs once every layer has accumulated) flushes them in one launch.  The workspaces that hold the partial tiles
+# stay alive in _DEFERRED_WS until then.
+_DEFERRED_WS = []
+
+
+def _launch_wgrad_deferring(launch, ws) -> None:
+    """Runs a weight-gradient launch with the library's reductions deferred (only around launches this module issues: a caller of the raw
+    C ABI keeps immediate reductions)."""
+    if not CFG.defer_wgrad_reduce or ws is None:
+        launch()
+        return
+    L.call("sp_wgrad_reduce_defer", 1)
+    try:
+        launch()
+    finally:
+        L.call("sp_wgrad_reduce_defer", 0)
+    if int(L.lib().sp_wgrad_reduce_pending()):
+        _DEFERRED_WS.append(ws)
+
+
+def flush_wgrad_reduce() -> None:
+    if _DEFERRED_WS or int(L.lib().sp_wgrad_reduce_pending()):
+        L.call("sp_wgrad_reduce_flush", 1, stream())
+        _DEFERRED_WS.clear()
+
+
 
 def _on_wgrad_stream(launch, tensors) -> None:
     """Experiment (config.CFG.wgrad_side_stream, off by default): the weight gradient of a layer depends on nothing the rest of the
@@ -980,7 +1009,7 @@ class _ConvFn(torch.autograd.Function):
             elif _wgrad_aside(h, w):
                 _on_wgrad_stream(launch_wgrad, [x, dz, ws])
             else:
-                launch_wgrad()
+                _launch_wgrad_deferring(launch_wgrad, ws)
             dh = dhb = _zero1(x.device)
         elif need[1]:
             # weight (+ bias) gradient accumulate into this layer's slots of the pass-wide arena; the spectral-norm
@@ -998,7 +1027,7 @@ class _ConvFn(torch.autograd.Function):
             elif _wgrad_aside(h, w) and pl.call.bank.direct_grads:
                 _on_wgrad_stream(launch_wgrad, [x, dz, ws])
             else:
-                launch_wgrad()
+                _launch_wgrad_deferring(launch_wgrad, ws)
             dh = _zero1(x.device)
             if direct_bias:
                 db = None                # accumulated in the bank's persistent slot; _SNBankFn.backward assigns bias.grad
@@ -1141,7 +1170,7 @@ class _ReusedLayerFn(torch.autograd.Function):
             if KERNEL_PROBE is not None:
                 _probed("wgrad", 2.0 * n * h * w * pl.cin * cout * ksize * ksize, False, launch, (ksize, cin_p, cout, h, w, n))
             else:
-                launch()
+                _launch_wgrad_deferring(launch, ws)
         else:
             dy = as_rows(dy, dt)
             b, k = x.shape

@@ -460,6 +460,69 @@ def test_conv1x1_streaming_weight_gradient_bf16(case):
     assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
 
 
+def test_deferred_slab_reductions_are_bit_identical_and_scoped():
+    """sp_wgrad_reduce_defer / _flush (include/sempyr.h): three streaming weight-gradient launches (1x1, 1x1 with a partial channel tile,
+    3x3 on the 8-channel input) queue their reductions and ONE flush launch adds them up - bit-identical to the immediate form; a
+    second launch onto a dW that is already queued keeps its own reduce kernel; a dropped queue launches nothing; outside the scope
+    the C ABI reduces at once."""
+    dt = torch.bfloat16
+    lib = L.lib()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    cases = [(64, 128, 1, 6, 64, 64), (72, 136, 1, 5, 32, 64), (8, 64, 3, 4, 64, 128)]
+    ops_in = []
+    for cin, cout, k, n, h, w in cases:
+        x = ops.nhwc_empty(n, cin, h, w, dt, "cuda").normal_(generator=g)
+        dy = ops.nhwc_empty(n, cout, h, w, dt, "cuda").normal_(generator=g)
+        floats = ops.wgrad_workspace_floats(n, h, w, cin, cout, k, dt)
+        assert floats > 0, "the case must run with pixel splits"
+        ops_in.append((x, dy, floats, cin, cout, k, n, h, w))
+
+    def run(deferred, twice=False):
+        outs, keep = [], []
+        for x, dy, floats, cin, cout, k, n, h, w in ops_in:
+            dw = torch.zeros(cout * k * k * cin, device="cuda")
+            db = torch.zeros(cout, device="cuda")
+            for _ in range(2 if twice else 1):
+                ws = torch.empty(floats, device="cuda")
+                keep.append(ws)
+                if deferred:
+                    L.call("sp_wgrad_reduce_defer", 1)
+                L.call("sp_conv2d_wgrad_accum", ops.ptr(x), ops.ptr(dy), ops.ptr(dw), ops.ptr(db), ops.ptr(ws), floats, n, h, w, cin, cout, cout, k,
+                       ops.sp_dtype(dt), ops.stream())
+                L.call("sp_wgrad_reduce_defer", 0)
+            outs.append((dw, db))
+        return outs, keep
+
+    ref, _ = run(False)
+    torch.cuda.synchronize()
+    assert int(lib.sp_wgrad_reduce_pending()) == 0
+    got, keep = run(True)
+    assert int(lib.sp_wgrad_reduce_pending()) == 3
+    torch.cuda.synchronize()
+    assert all(float(dw.abs().max()) == 0.0 for dw, _ in got), "nothing may reach dW before the flush"
+    L.call("sp_wgrad_reduce_flush", 1, ops.stream())
+    assert int(lib.sp_wgrad_reduce_pending()) == 0
+    torch.cuda.synchronize()
+    for (dw0, db0), (dw1, db1) in zip(ref, got):
+        assert float(dw0.abs().max()) > 0
+        assert torch.equal(dw0, dw1) and torch.equal(db0, db1)
+    # the same dW twice in one scope: the second launch reduces at once (stream order keeps the two sums apart)
+    ref2, _ = run(False, twice=True)
+    got2, keep2 = run(True, twice=True)
+    assert int(lib.sp_wgrad_reduce_pending()) == 3
+    L.call("sp_wgrad_reduce_flush", 1, ops.stream())
+    torch.cuda.synchronize()
+    for (dw0, db0), (dw1, db1) in zip(ref2, got2):
+        assert torch.allclose(dw0, dw1, rtol=1e-6, atol=1e-6 * float(dw0.abs().max())) and torch.allclose(db0, db1, rtol=1e-6, atol=1e-5)
+    # a dropped queue
+    got3, keep3 = run(True)
+    assert int(lib.sp_wgrad_reduce_pending()) == 3
+    L.call("sp_wgrad_reduce_flush", 0, ops.stream())
+    assert int(lib.sp_wgrad_reduce_pending()) == 0
+    torch.cuda.synchronize()
+    assert all(float(dw.abs().max()) == 0.0 for dw, _ in got3)
+
+
 POOL2_CASES = [(64, 64, 2, 16, 32, 0), (64, 64, 2, 8, 32, 0), (64, 128, 2, 16, 32, 0), (128, 128, 3, 8, 64, 0), (40, 256, 1, 16, 32, 0),
                (64, 128, 2, 16, 32, 2), (64, 64, 5, 64, 128, 0), (64, 128, 5, 64, 128, 2)]
 
