@@ -217,7 +217,8 @@ int sp_conv2d_wgrad_accum_pair(const void* x, const void* dy, float* dw_a, float
  *                                    arithmetic in the same order - bit-identical to the separate launches;
  *   sp_wgrad_reduce_flush(0, s)     drops the queue (a pass that was abandoned); sp_wgrad_reduce_pending() = its length;
  *   sp_wgrad_reduce_defer(0)        back to immediate reductions (what is queued stays queued until the flush).
- * The caller keeps every workspace alive until the flush and flushes on the stream the weight-gradient launches ran on. */
+ * The caller keeps every workspace alive until the flush and flushes on the stream the weight-gradient launches ran on.  The queue is
+ * host state of the process (not thread-safe: one thread drives the passes of a device, as torch's autograd does). */
 int sp_wgrad_reduce_defer(int32_t on);
 int sp_wgrad_reduce_flush(int32_t run, sp_stream_t stream);
 int sp_wgrad_reduce_pending(void);
