@@ -294,9 +294,8 @@ class ModelWrapper(object):
             self._vgg_ahead = None
             if features_next is not None:
                 if features_next_out is not None:                # (after the backward pass: it still read this iteration's features)
-                    with torch.no_grad():
-                        for dst, src in zip(features_next_out, features_next):
-                            dst.copy_(src)
+                    with torch.no_grad():                        # one multi-tensor launch instead of seven copies
+                        torch._foreach_copy_(list(features_next_out), list(features_next))
                     features_next = features_next_out
                 self._vgg_ahead = (next_images_real, next_images_real._version, features_next, self._mode_key())
         finally:
