@@ -103,57 +103,66 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ x
         for (int j = 0; j < FCI; ++j) fb[j] = PK * PA + g * PB + ((wb * FCI + j) * 16 + i16) * 4;
     }
 
+    // Every request of a step is UNCONDITIONAL (round 5): a chunk that does not exist - rows past the pixel range, channels past the
+    // tensor, the zero halo of a tap - re-reads the step's first pixel and is replaced by zeros when it is written to LDS, its validity
+    // kept as one bit per chunk.  With the loads under their per-lane conditions hipcc wrapped each one in an exec branch and waited
+    // `vmcnt(0)` behind it (the bias sums read the value at once): the requests of step k + 1 did not fly over the MFMAs of step k but
+    // one after the other in front of them.  The bias sums are taken where the registers are stored.
     uint4 ar[A_PER], br[B_PER];
+    unsigned amask = 0, bmask = 0;
     auto load_global = [&](int ks) {
         const long pb = p_begin + (long)ks * PK;                           // wave-uniform
         const char* dyb = reinterpret_cast<const char*>(dy + pb * LD_DY);
         const char* xb = reinterpret_cast<const char*>(x + pb * CIN);
-        const int left = (int)(p_end - pb);                                // rows [0, left) of this step exist
+        const int left = (int)(p_end - pb);                                // rows [0, left) of this step exist (left >= 1)
         const int rem0 = logw >= 0 ? (int)(pb & hw_mask) : (int)(pb % ((long)H * W));
+        amask = 0;
+        bmask = 0;
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (a_src[i] >= 0 && a_row[i] < left) v = *reinterpret_cast<const uint4*>(dyb + a_src[i]);
-            ar[i] = v;
-            if (do_bias) {
-                if constexpr (sizeof(T) == 2) {
-                    bsum[0] += bf16_bits_to_f32(v.x & 0xffffu); bsum[1] += bf16_bits_to_f32(v.x >> 16);
-                    bsum[2] += bf16_bits_to_f32(v.y & 0xffffu); bsum[3] += bf16_bits_to_f32(v.y >> 16);
-                    bsum[4] += bf16_bits_to_f32(v.z & 0xffffu); bsum[5] += bf16_bits_to_f32(v.z >> 16);
-                    bsum[6] += bf16_bits_to_f32(v.w & 0xffffu); bsum[7] += bf16_bits_to_f32(v.w >> 16);
-                } else {
-                    bsum[0] += __uint_as_float(v.x); bsum[1] += __uint_as_float(v.y);
-                    bsum[2] += __uint_as_float(v.z); bsum[3] += __uint_as_float(v.w);
-                }
-            }
+            const bool ok = a_src[i] >= 0 && a_row[i] < left;
+            amask |= (ok ? 1u : 0u) << i;
+            ar[i] = *reinterpret_cast<const uint4*>(dyb + (ok ? a_src[i] : 0));
         }
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (b_cok[i] && b_row[i] < left) {
-                int hh, ww;
-                if (logw >= 0) {                 // power-of-two H and W (every layer of this model): no integer division
-                    const int rem = (rem0 + b_row[i]) & (int)hw_mask;
-                    hh = (rem >> logw) + dr;
-                    ww = (rem & (W - 1)) + ds;
-                } else {
-                    const int rem = (int)((pb + b_row[i]) % ((long)H * W));
-                    hh = rem / W + dr;
-                    ww = rem % W + ds;
-                }
-                if ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) v = *reinterpret_cast<const uint4*>(xb + b_src[i]);
+            bool ok = b_cok[i] && b_row[i] < left;
+            int hh, ww;
+            if (logw >= 0) {                     // power-of-two H and W (every layer of this model): no integer division
+                const int rem = (rem0 + b_row[i]) & (int)hw_mask;
+                hh = (rem >> logw) + dr;
+                ww = (rem & (W - 1)) + ds;
+            } else {
+                const int rem = (int)((pb + b_row[i]) % ((long)H * W));
+                hh = rem / W + dr;
+                ww = rem % W + ds;
             }
-            br[i] = v;
+            ok = ok && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
+            bmask |= (ok ? 1u : 0u) << i;
+            br[i] = *reinterpret_cast<const uint4*>(xb + (ok ? b_src[i] : 0));
         }
     };
     auto store_lds = [&](int buf) {
         char* sb = smem + buf * STAGE;
 #pragma unroll
-        for (int i = 0; i < A_PER; ++i)
-            if (a_dst[i] >= 0) *reinterpret_cast<uint4*>(sb + a_dst[i]) = ar[i];
+        for (int i = 0; i < A_PER; ++i) {
+            const uint4 v = ((amask >> i) & 1u) ? ar[i] : make_uint4(0, 0, 0, 0);
+            if (do_bias) {
+                if constexpr (sizeof(T) == 2) {
+                    bsum[0] += h16_lo_to_f32(v.x); bsum[1] += h16_hi_to_f32(v.x);
+                    bsum[2] += h16_lo_to_f32(v.y); bsum[3] += h16_hi_to_f32(v.y);
+                    bsum[4] += h16_lo_to_f32(v.z); bsum[5] += h16_hi_to_f32(v.z);
+                    bsum[6] += h16_lo_to_f32(v.w); bsum[7] += h16_hi_to_f32(v.w);
+                } else {
+                    bsum[0] += __uint_as_float(v.x); bsum[1] += __uint_as_float(v.y);
+                    bsum[2] += __uint_as_float(v.z); bsum[3] += __uint_as_float(v.w);
+                }
+            }
+            if (a_dst[i] >= 0) *reinterpret_cast<uint4*>(sb + a_dst[i]) = v;
+        }
 #pragma unroll
         for (int i = 0; i < B_PER; ++i)
-            if (b_dst[i] >= 0) *reinterpret_cast<uint4*>(sb + b_dst[i]) = br[i];
+            if (b_dst[i] >= 0) *reinterpret_cast<uint4*>(sb + b_dst[i]) = ((bmask >> i) & 1u) ? br[i] : make_uint4(0, 0, 0, 0);
     };
 
     f32x4_t acc[FCO][FCI];
