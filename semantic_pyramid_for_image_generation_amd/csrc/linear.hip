@@ -93,18 +93,18 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const T* __restrict__
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 xv[u][0] = xv[u][1] = xv[u][2] = xv[u][3] = 0.f;
-                if (b + u < nb) {
-                    const T* xr = x + (long)(b0 + b + u) * ldx + k;
-                    if (vec) Elem<T>::ld4(xr, xv[u]);
-                    else {
+                // (unconditional: a batch row past the group re-reads its last row - its dy values in LDS are zeros; a load under
+                // `if (b + u < nb)` cost an exec branch and a full `vmcnt(0)` each)
+                const int br = b + u < nb ? b + u : nb - 1;
+                const T* xr = x + (long)(b0 + br) * ldx + k;
+                if (vec) Elem<T>::ld4(xr, xv[u]);
+                else {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) if (k + q < K) xv[u][q] = Elem<T>::ld(xr + q);
-                    }
+                    for (int q = 0; q < 4; ++q) if (k + q < K) xv[u][q] = Elem<T>::ld(xr + q);
                 }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if (b + u >= nb) break;
 #pragma unroll
                 for (int j = 0; j < LW_NR; ++j) {
                     const float d = dys[b + u][j];
