@@ -97,23 +97,31 @@ __global__ void act_avgpool2_bwd_kernel(const T* __restrict__ ga, const T* __res
         SP_DECODE(i, OH, OW, C)
         const long base = (((long)n * H + oh * 2) * W + ow * 2) * C + c;
         const long offs[4] = {0, C, (long)W * C, (long)W * C + C};
-        float p[V], g[V], t[V];
+        // all nine loads of an item are requested before the first is used (round 5: one window position at a time - load, mask,
+        // store - made four dependent round trips per item)
+        float p[V], g[4][V], t[4][V];
         for (int r = 0; r < V; ++r) p[r] = 0.f;
-        if (gp) {
-            VecIO<T, V>::ld(gp + (((long)n * OH + oh) * OW + ow) * C + c, p);
-            for (int r = 0; r < V; ++r) p[r] *= 0.25f;
+        if (gp) VecIO<T, V>::ld(gp + (((long)n * OH + oh) * OW + ow) * C + c, p);
+        const bool masked = ga != nullptr && act != SP_ACT_NONE;
+        if (ga) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) VecIO<T, V>::ld(ga + base + offs[k], g[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                for (int r = 0; r < V; ++r) g[k][r] = 0.f;
         }
+        if (masked) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) VecIO<T, V>::ld(x + base + offs[k], t[k]);
+        }
+        for (int r = 0; r < V; ++r) p[r] *= 0.25f;
+#pragma unroll
         for (int k = 0; k < 4; ++k) {
-            for (int r = 0; r < V; ++r) g[r] = 0.f;
-            if (ga) {
-                VecIO<T, V>::ld(ga + base + offs[k], g);
-                if (act != SP_ACT_NONE) {
-                    VecIO<T, V>::ld(x + base + offs[k], t);
-                    for (int r = 0; r < V; ++r) g[r] *= (t[r] > 0.f ? 1.f : slope);
-                }
-            }
-            for (int r = 0; r < V; ++r) g[r] += p[r];
-            VecIO<T, V>::st(dx + base + offs[k], g);
+            if (masked)
+                for (int r = 0; r < V; ++r) g[k][r] *= (t[k][r] > 0.f ? 1.f : slope);
+            for (int r = 0; r < V; ++r) g[k][r] += p[r];
+            VecIO<T, V>::st(dx + base + offs[k], g[k]);
         }
     }
 }
