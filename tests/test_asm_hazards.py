@@ -42,7 +42,7 @@ def test_checker_sees_a_premature_use():
     assert _checker().check(text.replace("v_add_u32_e32 v5, s0, v2", "v_add_u32_e32 v9, s0, v2")) == 0
 
 
-@pytest.mark.parametrize("source", ["conv_pp.hip", "conv_wgrad_rows.hip"])
+@pytest.mark.parametrize("source", ["conv_pp.hip", "conv_ppw.hip", "conv_wgrad_rows.hip"])
 def test_no_register_of_an_lds_read_in_flight_is_touched(source):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
