@@ -52,3 +52,36 @@ def test_tuning_keys_match_header_and_are_accepted():
     for v in keys.values():
         assert lib.sp_set_tuning(v, -1) == 0
     assert lib.sp_set_tuning(count, 0) != 0
+
+
+def test_linear_split_rule_and_reduce_queue_host_side():
+    """Host-only entry points (no device state): the split-K linear kernel's K range per block - the widest of 1024 / 512 / 256 / 128
+    that yields 256 blocks, one split for small layers (csrc/linear.hip: linear_ks) - seen through sp_linear_workspace (floats =
+    splits x batch x n), a forced width through SP_TUNE_LINEAR_KS; the deferred-reduction queue starts empty, defer / drop are
+    accepted without a GPU."""
+    lib = _lib.lib()
+    SP_BF16 = _lib.SP_BF16
+
+    def splits(b, k, n):
+        out = ctypes.c_int64(-1)
+        assert lib.sp_linear_workspace(b, k, n, SP_BF16, ctypes.byref(out)) == 0
+        assert out.value % (b * n) == 0
+        return out.value // (b * n)
+
+    # (batch, k, n) -> K range: VGG FC1 forward 1024 (25 splits), its input gradient 1024 (4), FC2 512 (8), 4096 -> 2048 256 (16),
+    # 1000 -> 4096 128 (8), the 365 -> 128 class mapping one split of 512
+    assert splits(40, 25088, 4096) == 25
+    assert splits(20, 4096, 25088) == 4
+    assert splits(40, 4096, 4096) == 8
+    assert splits(20, 4096, 2048) == 16
+    assert splits(20, 1000, 4096) == 8
+    assert splits(20, 365, 128) == 1
+    key = _lib.TUNE_KEYS["SP_LINEAR_KS"]
+    try:
+        assert lib.sp_set_tuning(key, 128) == 0
+        assert splits(40, 4096, 4096) == 32
+    finally:
+        lib.sp_set_tuning(key, -1)
+    assert lib.sp_wgrad_reduce_pending() == 0
+    assert lib.sp_wgrad_reduce_defer(1) == 0 and lib.sp_wgrad_reduce_defer(0) == 0
+    assert lib.sp_wgrad_reduce_flush(0, None) == 0 and lib.sp_wgrad_reduce_pending() == 0
