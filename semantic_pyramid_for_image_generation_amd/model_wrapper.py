@@ -419,6 +419,10 @@ class ModelWrapper(object):
                 l_g, l_rec, l_div = self._g_rest(fake, st["noise_g"], lab_d, st["masks"], feats, w_rec, w_div, st.get("images_next"),
                                                  st["feats_real"], ahead=ahead)
             st["g_grads"] = [p.grad for p in self._g_params]
+        except BaseException:
+            ops.drop_wgrad_reduce()            # queued slab reductions of the abandoned capture point into its (released) pool
+            self._graph_state = None
+            raise
         finally:
             self._capturing = False
             self._vgg_ahead = None

@@ -49,7 +49,11 @@ def set_loss_scale(value: float, growth: float = 2.0, backoff: float = 0.5, grow
     clean optimizer steps it is multiplied by `growth`."""
     _STATE["loss_scale"] = float(value)
     _STATE["ls_policy"] = (float(growth), float(backoff), int(growth_interval))
-    _SCALERS.clear()
+    # existing device states are re-initialised IN PLACE: captured graphs have their address baked in (backward seeds, the unscale pass,
+    # the spectral-norm backward's 1 / scale, the overflow flag) - dropping the tensor would leave replays on freed memory while the
+    # optimizer guard watched a new one (round-5 ADVICE)
+    for sc in _SCALERS.values():
+        sc.state.copy_(torch.tensor([float(value), 1.0 / float(value), 0.0, 0.0, 0.0], dtype=torch.float32))
 
 
 class LossScaler:
@@ -610,6 +614,7 @@ class SpectralNormBank:
         if key != self._key:
             self._build(dtype, device)
             self._key = key
+        drop_wgrad_reduce()                   # (no reduction of an earlier backward pass is pending here unless that pass was abandoned)
         pack = torch.empty(self.pack_bytes, dtype=torch.uint8, device=device)
         scratch = torch.empty(self.scratch_floats, dtype=torch.float32, device=device)
         table, blocks = (self.table_dev, self.pack_blocks) if not skip_pack else self._unpacked_table(skip_pack)
@@ -833,15 +838,20 @@ _WGRAD_STREAMS = {}
 _DEFERRED_WS = []
 
 
-def _launch_wgrad_deferring(launch, ws) -> None:
+def _launch_wgrad_deferring(launch, ws, defer_ok: bool = True) -> None:
     """Runs a weight-gradient launch with the library's reductions deferred (only around launches this module issues: a caller of the raw
-    C ABI keeps immediate reductions)."""
-    if not CFG.defer_wgrad_reduce or ws is None:
+    C ABI keeps immediate reductions).  defer_ok = False: a launch whose bias slot goes back to AUTOGRAD (a bank without direct
+    gradients): autograd may add to it or sum it with another contribution before the bank's backward node flushes the queue, so its
+    reduction runs at once (round-5 ADVICE)."""
+    if not CFG.defer_wgrad_reduce or ws is None or not defer_ok:
         launch()
         return
     L.call("sp_wgrad_reduce_defer", 1)
     try:
         launch()
+    except BaseException:
+        drop_wgrad_reduce()                 # an abandoned pass: nothing queued may outlive its workspaces
+        raise
     finally:
         L.call("sp_wgrad_reduce_defer", 0)
     if int(L.lib().sp_wgrad_reduce_pending()):
@@ -851,6 +861,16 @@ def _launch_wgrad_deferring(launch, ws) -> None:
 def flush_wgrad_reduce() -> None:
     if _DEFERRED_WS or int(L.lib().sp_wgrad_reduce_pending()):
         L.call("sp_wgrad_reduce_flush", 1, stream())
+        _DEFERRED_WS.clear()
+
+
+def drop_wgrad_reduce() -> None:
+    """Forgets queued reductions without running them.  The queue is process-wide host state holding raw pointers (csrc/reduce_queue.hip);
+    a backward pass or a graph capture that raised midway leaves entries that point into freed arenas or an abandoned capture pool, and
+    the next flush would add stale slabs to whatever lives there now (round-5 ADVICE).  Called where no entry can be legitimate: at the
+    start of every forward of a bank (every backward pass ends with its flush) and in the failure paths of the capture."""
+    if _DEFERRED_WS or int(L.lib().sp_wgrad_reduce_pending()):
+        L.call("sp_wgrad_reduce_flush", 0, stream())
         _DEFERRED_WS.clear()
 
 
@@ -1027,7 +1047,7 @@ class _ConvFn(torch.autograd.Function):
             elif _wgrad_aside(h, w) and pl.call.bank.direct_grads:
                 _on_wgrad_stream(launch_wgrad, [x, dz, ws])
             else:
-                _launch_wgrad_deferring(launch_wgrad, ws)
+                _launch_wgrad_deferring(launch_wgrad, ws, defer_ok=db is None or pl.call.bank.direct_grads)
             dh = _zero1(x.device)
             if direct_bias:
                 db = None                # accumulated in the bank's persistent slot; _SNBankFn.backward assigns bias.grad
@@ -1170,7 +1190,7 @@ class _ReusedLayerFn(torch.autograd.Function):
             if KERNEL_PROBE is not None:
                 _probed("wgrad", 2.0 * n * h * w * pl.cin * cout * ksize * ksize, False, launch, (ksize, cin_p, cout, h, w, n))
             else:
-                _launch_wgrad_deferring(launch, ws)
+                _launch_wgrad_deferring(launch, ws, defer_ok=db is None or pl.call.bank.direct_grads)
         else:
             dy = as_rows(dy, dt)
             b, k = x.shape

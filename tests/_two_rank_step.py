@@ -279,7 +279,8 @@ def launch(out_path, world=2, timeout_s=900.0):
                               "--channel-factor", "8", "--no-cpu-baseline", "--no-sub-records", "--no-kernel-probe"],
                              env=env, capture_output=True, text=True, timeout=900)
         line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-        merged["bench_two_ranks"] = {"returncode": out.returncode, "line": json.loads(line[-1]) if line else None, "stderr_tail": out.stderr[-1500:]}
+        merged["bench_two_ranks"] = {"returncode": out.returncode, "line": json.loads(line[-1]) if line else None,
+                                     "line_chars": len(line[-1]) if line else 0, "stderr_tail": out.stderr[-1500:]}
     except Exception as exc:
         merged["bench_two_ranks"] = {"returncode": -1, "line": None, "stderr_tail": "%s: %s" % (type(exc).__name__, exc)}
     tmp = out_path + ".tmp"

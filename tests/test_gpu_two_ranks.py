@@ -52,6 +52,7 @@ def test_bench_two_rank_dry_run_on_one_gpu():
     line = rec["line"]
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak" and line["config"]["global_batch"] == 8, line
     mg = line["multi_gpu"]
-    assert len(mg["per_rank_images_per_sec"]) == 2 and all(v > 0 for v in mg["per_rank_images_per_sec"]), mg
+    assert len(mg["per_rank"]) == 2 and all(v > 0 for v in mg["per_rank"]), mg
+    assert rec.get("line_chars", 0) < 4096, rec.get("line_chars")          # the compact line (bench.compact_line), not the full record
     assert mg["allreduce_ms_d"] is not None and mg["allreduce_ms_g"] is not None and mg["grad_bytes_d"] > 0 and mg["grad_bytes_g"] > 0, mg
     assert abs(line["value"] - 8 * line["steps"] / (line["ms_per_step"] * line["steps"] / 1e3)) <= 0.02 * line["value"]
