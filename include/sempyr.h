@@ -79,13 +79,15 @@ int sp_version(void);
  *                            (conv_ppw.hip) where the round count favours 16-row items; 0 = off (tall<2,16> / the 8-row form), 2 = wherever eligible
  *   SP_TUNE_LINEAR_KS        K range per block of the split-K MFMA linear kernel: 1024 / 512 / 256 / 128 (default: the widest that yields 256 blocks)
  *   SP_TUNE_BN_ITERS         pixels per thread of the elementwise BatchNorm passes (grid sizing; default 2)
+ *   SP_TUNE_CONV_PP_SPLIT    0 = the ping-pong 3x3 kernel never splits the work items of its last, partial round along K (default 1: it does
+ *                            where sp_conv_params.workspace holds the partial tiles - sp_conv2d_workspace() says how many bytes)
  *   SP_TUNE_CONV_PP_PRIO     bit 0: s_setprio 1 around every MFMA segment of the ping-pong kernel (default 1); bit 1: static priority 1
  *                            for the second-dispatched half of the block */
 enum { SP_TUNE_CONV_TALL = 0, SP_TUNE_IGEMM_DMA = 1, SP_TUNE_WGRAD_ROWS = 2, SP_TUNE_DETERMINISTIC = 3,
        SP_TUNE_SPLITK_TARGET = 4, SP_TUNE_SPLITK_MINSTEPS = 5, SP_TUNE_CONV1X1_DIRECT = 6, SP_TUNE_CONV_SHORT = 7,
        SP_TUNE_WGRAD9_BLOCKS = 8, SP_TUNE_WGRAD_BLOCKS = 9, SP_TUNE_WGRAD_MINSTEPS = 10, SP_TUNE_WGRAD_SMALL_M = 11,
        SP_TUNE_WGRAD_K1_TILE64 = 12, SP_TUNE_WGRAD_ROWS_THIN = 13, SP_TUNE_WGRAD_ROWS_BLOCKS = 14, SP_TUNE_WGRAD_ROWS_SLABS = 15,
-       SP_TUNE_CONV_STAGGER = 16, SP_TUNE_CONV1X1_SPLITK = 17, SP_TUNE_WGRAD1X1 = 18, SP_TUNE_CONV_CIN8 = 19, SP_TUNE_CONV_THINCO = 20, SP_TUNE_CONV_PP = 21, SP_TUNE_CONV_PP_PRIO = 22, SP_TUNE_WGRAD_PP = 23, SP_TUNE_BN_ITERS = 24, SP_TUNE_IGEMM_TILE = 25, SP_TUNE_CONV_PPW = 26, SP_TUNE_LINEAR_KS = 27, SP_TUNE_COUNT = 28 };
+       SP_TUNE_CONV_STAGGER = 16, SP_TUNE_CONV1X1_SPLITK = 17, SP_TUNE_WGRAD1X1 = 18, SP_TUNE_CONV_CIN8 = 19, SP_TUNE_CONV_THINCO = 20, SP_TUNE_CONV_PP = 21, SP_TUNE_CONV_PP_PRIO = 22, SP_TUNE_WGRAD_PP = 23, SP_TUNE_BN_ITERS = 24, SP_TUNE_IGEMM_TILE = 25, SP_TUNE_CONV_PPW = 26, SP_TUNE_LINEAR_KS = 27, SP_TUNE_CONV_PP_SPLIT = 28, SP_TUNE_COUNT = 29 };
 int sp_set_tuning(int32_t key, int32_t value);
 const char* sp_last_error_string(void);
 /* Name of the kernel (route) the last sp_conv2d_igemm / sp_conv2d_wgrad* call of THIS thread launched ("" before the first one):
@@ -111,7 +113,8 @@ typedef struct sp_conv_params {
     const void* mask_src;   /* like y, or NULL                               */
     float mask_neg_slope;
     int32_t n, h, w_, cin_p, cout, ldy, ksize, act, dtype;
-    void* workspace;        /* optional fp32 scratch of sp_conv2d_workspace() bytes: lets small-spatial layers split K; NULL = never */
+    void* workspace;        /* optional fp32 scratch of sp_conv2d_workspace() bytes: lets small-spatial layers split K, and the 16-bit 3x3
+                             * ping-pong kernel split the items of its last partial round (conv_pp.hip, "tail split"); NULL = never */
     int64_t workspace_bytes;
     int32_t pool2;          /* 2: y is [n][h/2][w/2][ldy] and y = act(maxpool2x2(conv) + bias) - conv -> ReLU -> nn.MaxPool2d(2) of
                              * the frozen VGG-16 stages (models.py:158-216) when the unpooled tensor is not needed (no-grad

@@ -25,7 +25,7 @@ TUNE_KEYS = {"SP_CONV_TALL": 0, "SP_IGEMM_DMA": 1, "SP_WGRAD_ROWS": 2, "SP_DETER
              "SP_SPLITK_MINSTEPS": 5, "SP_CONV1X1_DIRECT": 6, "SP_CONV_SHORT": 7, "SP_WGRAD9_BLOCKS": 8, "SP_WGRAD_BLOCKS": 9,
              "SP_WGRAD_MINSTEPS": 10, "SP_WGRAD_SMALL_M": 11, "SP_WGRAD_K1_TILE64": 12, "SP_WGRAD_ROWS_THIN": 13,
              "SP_WGRAD_ROWS_BLOCKS": 14, "SP_WGRAD_ROWS_SLABS": 15, "SP_CONV_STAGGER": 16, "SP_CONV1X1_SPLITK": 17, "SP_WGRAD1X1": 18, "SP_CONV_CIN8": 19, "SP_CONV_THINCO": 20,
-             "SP_CONV_PP": 21, "SP_CONV_PP_PRIO": 22, "SP_WGRAD_PP": 23, "SP_BN_ITERS": 24, "SP_IGEMM_TILE": 25, "SP_CONV_PPW": 26, "SP_LINEAR_KS": 27}
+             "SP_CONV_PP": 21, "SP_CONV_PP_PRIO": 22, "SP_WGRAD_PP": 23, "SP_BN_ITERS": 24, "SP_IGEMM_TILE": 25, "SP_CONV_PPW": 26, "SP_LINEAR_KS": 27, "SP_CONV_PP_SPLIT": 28}
 
 
 class SpConvParams(ctypes.Structure):

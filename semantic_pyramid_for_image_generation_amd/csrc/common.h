@@ -175,6 +175,9 @@ static inline int sp_tune(int key, int dflt) { return sp_g_tune[key] >= 0 ? sp_g
 static inline bool sp_deterministic(int dtype) { return sp_g_tune[SP_TUNE_DETERMINISTIC] >= 0 ? sp_g_tune[SP_TUNE_DETERMINISTIC] != 0 : dtype == SP_F32; }
 // conv_pp.hip: SP_OK after launching, 1 if the shape is not covered (bf16 3x3, Cout > 64, th x 32 patches with th = 8 / 16)
 int sp_conv_pp_launch(const sp_conv_params& p, int th, hipStream_t s);
+long sp_conv_pp_split_workspace(int n, int h, int w, int cin_p, int cout);   // conv_pp.hip: scratch for the K-split of the last partial round
+long sp_conv_pp_split_workspace_w16(int n, int h, int cin_p, int cout);      // ... of its 16-pixel-wide tiles
+long sp_conv_pp_rounds100(long total, int cin_p, long workspace_bytes);      // ... and what a launch of `total` 8-row items costs with it
 int sp_conv_ppw_launch(const sp_conv_params& p, hipStream_t s);      // conv_ppw.hip: 128 co x 16 x 32 px, 64 co x 4 rows per wave
 int sp_conv_ppw_covers(const sp_conv_params& p);                    // ... whether it takes the launch at all (shape, epilogue)
 // reduce_queue.hip (compiled once, shared by both flavours): true = the slab reduction was queued for sp_wgrad_reduce_flush

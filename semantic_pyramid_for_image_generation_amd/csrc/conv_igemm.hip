@@ -1607,7 +1607,9 @@ int dispatch(const sp_conv_params& p, hipStream_t s) {
             if (tall_ok && ppw_mode && pp_mode == 1 && sp_conv_ppw_covers(p)) {
                 const int kch = (p.cin_p + 31) / 32;
                 const long ratio = kch >= 12 ? 172 : kch >= 6 ? 185 : kch >= 3 ? 194 : 204;
-                if (ppw_mode == 2 || ratio * rt < 100 * rh) {
+                // (the 8-row form splits the items of a last, partial round along K - conv_pp.hip: its cost is no longer whole rounds)
+                const long rh100 = sp_conv_pp_rounds100(2 * bt, p.cin_p, p.workspace != nullptr ? p.workspace_bytes : 0);
+                if (ppw_mode == 2 || ratio * rt < rh100) {
                     const int rc = sp_conv_ppw_launch(p, s);
                     if (rc != 1) return rc;
                 }
@@ -1676,6 +1678,15 @@ extern "C" int sp_conv2d_workspace(int32_t n, int32_t h, int32_t w_, int32_t cin
     const long M = (long)n * h * w_;
     const int dma_mode = sp_tune(SP_TUNE_IGEMM_DMA, 1);
     const bool halo_path = ksize == 3 && cout > 32 && h % HALO_TH == 0 && w_ % HALO_TW == 0;
+    if (halo_path && dtype != SP_F32 && sp_tune(SP_TUNE_CONV_PP, 1)) {
+        // the ping-pong kernel's K-split of its last partial round (conv_pp.hip): partial tiles of the tail items
+        *bytes_out = sp_conv_pp_split_workspace(n, h, w_, cin_p, cout);
+        return SP_OK;
+    }
+    if (ksize == 3 && w_ == 16 && cout > 64 && dtype != SP_F32 && (sp_tune(SP_TUNE_CONV_PP, 1) == 1 || sp_tune(SP_TUNE_CONV_PP, 1) == 3)) {
+        const long b16 = sp_conv_pp_split_workspace_w16(n, h, cin_p, cout);       // the same kernel on 16 x 16-pixel tiles
+        if (b16 > 0) { *bytes_out = b16; return SP_OK; }
+    }
     if (ksize != 3 || halo_path || cout <= 16 || M > 8192 || dma_mode == 0) return SP_OK;
     int co_t = cout <= 32 ? 32 : 64, px_t = cout <= 64 ? 256 : 64;
     if (cout > 64) {                                                     // (the tile dispatch() picks for these layers)

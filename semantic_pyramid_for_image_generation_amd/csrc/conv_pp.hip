@@ -41,6 +41,54 @@ constexpr int PP_TW_WIDE = 32;
 constexpr int PP_NUM_CU = 256;                 // MI355X
 constexpr int PP_BIAS_MAX = 1024;              // output channels whose bias fits the LDS copy
 
+// ---- K-split of the LAST, partial round of work items ("tail split", round 6) ----
+// The block is persistent with one block per CU, so a launch takes ceil(items / 256) rounds: 320 items (512 -> 512 on 32 x 32 maps at
+// batch 20) cost two rounds with 3/4 of the chip idle in the second; at the metric's batch of 20 most mid-network layers sit at 1.25 /
+// 2.5 rounds, which batch 32 does not (profiles/README.md, round 6).  With sk_parts = P > 1 the R = items mod 256 items of the last round
+// are cut into P pieces along K (P = min(4, 256 / R) consecutive ranges of channel chunks) and piece q of tail item j goes to the block
+// with the physical index j * P + q - the DMA stream runs into a piece like into any other item.  Pieces q < P - 1 are their block's
+// FIRST piece of work: they leave their raw fp32 accumulators in a slab of the caller's workspace (sp_conv_params.workspace) - stores
+// that drain while the block's first full item computes - and at the end of that item the wave raises a per-(item, wave) counter
+// (behind `s_waitcnt vmcnt(0)`: the stores are at the memory side).  Piece P - 1 is its block's LAST piece of work (and the highest
+// block index of the item, so every block it depends on was dispatched before it): it finds the counter raised a whole item ago, adds
+// the slabs in piece order (a fixed order: the result does not depend on timing) and runs the item's ordinary epilogue.  (A first
+// version ran every piece last: the owner then waits for store -> signal -> load round trips at the very end of the launch, 10 - 20
+// us, more than the split saves below K = 512.)  Slabs and counters move with agent-scope relaxed atomics (sc1: through the XCD's L2 to
+// the memory side - the L2s of different XCDs are not coherent for plain accesses); the waiter zeroes the counter again, so the
+// counters (a static array, zero at load) are clean whenever no launch is in flight.
+constexpr int PP_SK_MAX_PARTS = 4;
+constexpr int PP_SK_SLAB_FLOATS = 8 * 64 * 64;           // one piece: 8 waves x 64 lanes x 64 accumulator registers = 128 KB
+__device__ int g_pp_sk_flags[PP_NUM_CU * 8];
+
+struct PPSplit { int parts, tail_items, grid; };
+// the plan for `total` items of `kchunks` chunks each; parts <= 1: no split (grid: the unsplit launch's).  total < 256 (less than one
+// round: e.g. 80 items of 128 co x 16 x 16 px for 512 -> 512 on 16 x 16 maps at batch 20): every item is a tail item and the grid is
+// tail_items * parts blocks of one piece each (SP_TUNE_CONV_PP_SPLIT = 2 keeps the split to launches of at least one full round).
+inline PPSplit pp_split_plan(int total, int kchunks, long workspace_bytes) {
+    PPSplit r{0, 0, total < PP_NUM_CU ? total : PP_NUM_CU};
+    if (r.grid >= 8) r.grid -= r.grid % 8;                 // (the XCD remap of the round-robin items wants a multiple of 8)
+    const int mode = sp_tune(SP_TUNE_CONV_PP_SPLIT, 1);
+    if (!mode || total <= 0 || (total < PP_NUM_CU && mode == 2)) return r;
+    const int R = total % PP_NUM_CU;
+    if (R == 0) return r;
+    int pmax = PP_NUM_CU / R;
+    if (pmax > PP_SK_MAX_PARTS) pmax = PP_SK_MAX_PARTS;
+    // the last round takes ~3.7 us per chunk of its longest piece + 4 - 6 us per piece handed over (measured, profiles/README.md round 6:
+    // the slabs of P - 1 contributors drain through the memory side, the owner fetches them one round trip each); a piece has at
+    // least two chunks, and the split must save at least a twentieth of the round
+    int P = 1;
+    long best = 37L * kchunks;
+    const long handover = total >= 2 * PP_NUM_CU ? 40 : 60;  // (two full items in front of the owner's piece hide more of it)
+    for (int q = 2; q <= pmax && kchunks / q >= 2; ++q) {
+        const long c = 37L * ((kchunks + q - 1) / q) + handover * (q - 1);
+        if (c < best && 20 * c < 19 * 37L * kchunks) { best = c; P = q; }
+    }
+    if (P < 2 || (long)R * (P - 1) * PP_SK_SLAB_FLOATS * 4 > workspace_bytes) return r;
+    r.parts = P; r.tail_items = R;
+    r.grid = total < PP_NUM_CU ? R * P : PP_NUM_CU;
+    return r;
+}
+
 template <typename T, int WCO, int FW = 2>
 struct PPGeom {
     static constexpr int E = 16 / (int)sizeof(T), KC = 4 * E;
@@ -80,7 +128,7 @@ constexpr int pp_group_index(int h, int dr, int rw) {
 // 18 K instructions in ~1 100 basic blocks around a 1.7 K-instruction loop; measured with compile-time assumptions in its place
 // (scratch: -DPP_ASSUME_SIMPLE), a launch of 128->128 @128^2 drops from 170 K to 148 K cycles per block, 64->128 from 111 K to 92 K.
 template <typename T, int WCO, int PRIO, bool TIMING = false, bool DMA_IN_L = true, bool FAST = false, int FW = 2, bool TAIL = false, bool IDX = false>
-__global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int cotiles, int total, int prio) {
+__global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int cotiles, int total, int prio, int sk_parts) {
     static_assert(!IDX || (!FAST && sizeof(T) == 2), "pool_idx: the general 16-bit epilogue");
     static_assert(!TAIL || (FAST && WCO == 1 && FW == 2), "the fused 1x1 tail lives in the 64-channel FAST form");
     using G = PPGeom<T, WCO, FW>;
@@ -103,8 +151,20 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
     const int GR = gridDim.x;
     int bid = blockIdx.x;
     if ((GR & 7) == 0) bid = (bid & 7) * (GR >> 3) + (bid >> 3);
-    const int my_items = (total - bid + GR - 1) / GR;
-    const int nchunks = my_items * kchunks;
+    // tail split (see the top of the file): the first full_total items go round robin as ever, the rest in K pieces
+    const int full_total = sk_parts > 1 ? (total / GR) * GR : total;
+    const int my_items = (full_total - bid + GR - 1) / GR;
+    int t_item = -1, t_part = 0, t_k0 = 0, t_k1 = 0, t_j = 0;
+    if (sk_parts > 1 && (int)blockIdx.x < (total - full_total) * sk_parts) {
+        t_j = (int)blockIdx.x / sk_parts;
+        t_part = (int)blockIdx.x - t_j * sk_parts;
+        t_item = full_total + t_j;
+        t_k0 = t_part * kchunks / sk_parts;
+        t_k1 = (t_part + 1) * kchunks / sk_parts;
+    }
+    const bool has_tail = t_item >= 0;
+    const bool t_owner = t_part == sk_parts - 1;            // the piece that adds the others and runs the epilogue
+    const int nchunks = my_items * kchunks + (has_tail ? t_k1 - t_k0 : 0);
     if (nchunks <= 0) return;
 
     // ---- bias -> LDS (fp32, zero padded to whole co-tiles), before the first LDS-DMA is in flight
@@ -148,10 +208,14 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
     // work item -> (co-tile, patch column, patch row, image): item k of this block is number bid + k * GR; the mixed-radix digits
     // advance by the digits of GR with carries (a dozen scalar instructions per item instead of three integer divisions per use)
     struct Coords { int co_i, tx_i, ty_i, n; };
-    Coords cur, nxt;
+    Coords cur, nxt, tailc;
     int s_co, s_tx, s_ty, s_n;
     {
-        int t = bid;
+        int t = has_tail ? t_item : 0;
+        tailc.co_i = t % cotiles; t /= cotiles;
+        tailc.tx_i = t % tiles_x; t /= tiles_x;
+        tailc.ty_i = t % tiles_y; tailc.n = t / tiles_y;
+        t = bid;
         cur.co_i = t % cotiles; t /= cotiles;
         cur.tx_i = t % tiles_x; t /= tiles_x;
         cur.ty_i = t % tiles_y; cur.n = t / tiles_y;
@@ -168,7 +232,22 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
         r.n = c.n + s_n + cy;
         return r;
     };
-    nxt = advance(cur);
+    // item number `it` of this block: its my_items full items (round robin) with the tail piece in front of them (a contributing piece)
+    // or behind them (the piece that owns the item's epilogue)
+    int it = 0;
+    const int t_pos = has_tail ? (t_owner ? my_items : 0) : -1;
+    Coords strided = cur;                                   // the next full item to hand out
+    auto item_coords = [&](int idx, bool& is_tail) {
+        is_tail = idx == t_pos;
+        if (is_tail) return tailc;
+        const Coords c = strided;
+        strided = advance(strided);
+        return c;
+    };
+    bool cur_is_tail, nxt_is_tail;
+    cur = item_coords(0, cur_is_tail);
+    nxt = item_coords(1, nxt_is_tail);
+    bool sk_signal_due = false;                             // a contributing piece whose stores are in flight
     auto set_halo_desc = [&](const Coords& c) {
         const int n = c.n, ty0 = c.ty_i * TH, tx0 = c.tx_i * PP_TW;
         int l4 = lane >> 2;
@@ -250,17 +329,19 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
     // ---- prologue: chunk 0's halo, weight stages 0, 1 and 2
     set_halo_desc(cur);
     set_w_desc(cur);
+    int kc = cur_is_tail ? t_k0 : 0;                        // chunk of the current item; a tail piece starts inside its item
+    int kc_end = cur_is_tail ? t_k1 : kchunks;
 #pragma unroll
-    for (int i = 0; i < HPW; ++i) issue_halo_piece(i, true, 0, 0);
+    for (int i = 0; i < HPW; ++i) issue_halo_piece(i, true, kc * KC, 0);
 #pragma unroll
     for (int ds = 0; ds < 3; ++ds)
 #pragma unroll
-        for (int i = 0; i < W_PER; ++i) issue_w_piece(i, true, 0, ds, ds);
+        for (int i = 0; i < W_PER; ++i) issue_w_piece(i, true, kc * KC, ds, ds);
     wait_vmcnt<2 * W_PER>();                                // halo 0 and stage 0 landed (this wave's pieces); stages 1, 2 may fly
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the bias copy
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    bias_fetch(true, cur.co_i * CO_T);
+    bias_fetch(!(cur_is_tail && !t_owner), cur.co_i * CO_T);   // (a tail piece that only contributes starts from zero)
     auto acc_from_bias = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -290,14 +371,13 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
     if constexpr (TIMING) tprev = __builtin_readcyclecounter();
     float vmax = 0.f;                                       // SP_F8: running max of this lane's outputs (merged once per block at the end)
     int g4 = 0;                                             // weight ring slot of the stage being computed (stage index mod 4)
-    int kc = 0;
     const bool vec_ok = ((p.ldy & 3) == 0) && ((p.cout & 3) == 0);
     for (int gc = 0; gc < nchunks; ++gc) {
         const bool more_chunks = gc + 1 < nchunks;
-        const bool item_ends = kc + 1 == kchunks;
+        const bool item_ends = kc + 1 == kc_end;
         if constexpr (TIMING) stamp_on = kc != 0 && !item_ends;
         const unsigned hb = (unsigned)((gc & 1) * HALO_BUF);
-        const int c0_next = item_ends ? 0 : (kc + 1) * KC;
+        const int c0_next = item_ends ? (nxt_is_tail ? t_k0 * KC : 0) : (kc + 1) * KC;
         auto stage = [&](auto sc) {
             constexpr int st = decltype(sc)::value;        // stage inside the chunk = tap column
             constexpr int NREAD = 12 + FW * NB;
@@ -373,6 +453,13 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
         stage(std::integral_constant<int, 0>{});
         stage(std::integral_constant<int, 1>{});
         stage(std::integral_constant<int, 2>{});
+        if (sk_signal_due && !item_ends) {
+            // the first chunk behind a contributing piece: its slab stores were issued three stages ago - raise the counter now (an
+            // owner with a single full item in front of its piece asks for it one item after this block started)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(g_pp_sk_flags + t_j * 8 + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sk_signal_due = false;
+        }
         if (item_ends) {
             // BOTH epilogues in one barrier interval.  After its last MFMA segment the leading half passes the barrier, runs its
             // epilogue and the next item's first LOAD segment; the other half is in its last MFMA segment meanwhile and would then
@@ -383,6 +470,50 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
             const long pix0 = ((long)n * H + ty0 + RW * wpx) * W + tx0 + (lane & 15);
             const int co_b = co0 + wco * 64 + (lane >> 4) * 16;          // this lane's 16 consecutive channels
             const bool wide = FAST ? co_b < p.cout : vec_ok && (p.ldy & 7) == 0 && co_b + 16 <= p.cout;
+            bool run_epilogue = true;
+            if (sk_signal_due) {                                         // the item behind a contributing piece: its slab has had a whole item to drain
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(g_pp_sk_flags + t_j * 8 + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sk_signal_due = false;
+            }
+            if (cur_is_tail && sk_parts > 1) {                           // wave-uniform
+                // tail split: pieces 0 .. P - 2 hand their raw accumulators over, piece P - 1 adds them (in piece order) and goes on
+                int woff = wave * 4096 + lane;
+                asm volatile("" : "+v"(woff));                           // (computed HERE: hoisted out of the chunk loop, the sixty-odd
+                                                                         // addresses below stay live across it and spill)
+                float* slab0 = reinterpret_cast<float*>(p.workspace) + ((long)t_j * (sk_parts - 1)) * PP_SK_SLAB_FLOATS + woff;
+                int* flag = g_pp_sk_flags + t_j * 8 + wave;
+                if (!t_owner) {
+                    float* dst = slab0 + (long)t_part * PP_SK_SLAB_FLOATS;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < NFR; ++j)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                __hip_atomic_store(dst + ((i * NFR + j) * 4 + r) * 64, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    sk_signal_due = true;                                // raised at the end of the next item (or of the block)
+                    run_epilogue = false;
+                } else {
+                    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sk_parts - 1) __builtin_amdgcn_s_sleep(8);
+                    asm volatile("" ::: "memory");
+#pragma unroll 1
+                    for (int q = 0; q < sk_parts - 1; ++q) {
+                        const float* src = slab0 + (long)q * PP_SK_SLAB_FLOATS;
+                        // all 64 loads of a slab in flight: one round trip to the memory side per slab (the stage's fragment registers are
+                        // free here; two trips of 32 cost the owner of a four-piece item 12 us)
+                        float t[NFR * 16];
+#pragma unroll
+                        for (int k = 0; k < NFR * 16; ++k)
+                            t[k] = __hip_atomic_load(src + k * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                        for (int k = 0; k < NFR * 16; ++k) acc[k / (NFR * 4)][(k >> 2) % NFR][k & 3] += t[k];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (lane == 0) __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next launch
+                }
+            }
+            if (run_epilogue) {
             if (up) {                                                    // the 1/4 of the average-pooling gradient
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -626,12 +757,16 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
                     }
                 }
             });
+            }                                               // run_epilogue
             stamp(10);
-            kc = 0;
+            ++it;
             cur = nxt;
-            nxt = advance(nxt);
+            cur_is_tail = nxt_is_tail;
+            kc = cur_is_tail ? t_k0 : 0;
+            kc_end = cur_is_tail ? t_k1 : kchunks;
+            nxt = item_coords(it + 1, nxt_is_tail);          // (past the block's last item: coordinates nobody uses)
             stamp(5);
-            bias_fetch(more_chunks, cur.co_i * CO_T);       // (after the epilogue's own reads of the bias / scale tables)
+            bias_fetch(more_chunks && !(cur_is_tail && !t_owner), cur.co_i * CO_T);   // (after the epilogue's own reads of the bias / scale tables)
             acc_from_bias();
             stamp(8);
             if (half_b) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
@@ -640,6 +775,10 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
         }
     }
     if (!half_b) __builtin_amdgcn_s_barrier();              // the barrier the other half passes after its last MFMA segment
+    if (sk_signal_due) {                                    // (a contributing piece with no item behind it)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(g_pp_sk_flags + t_j * 8 + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if constexpr (G::F8) {
         // one atomic per BLOCK on the running maximum (per item and wave they serialise on one L2 word: 10 K atomics = 100+ us)
         if (p.y8_amax != nullptr) {
@@ -683,16 +822,51 @@ int launch_pp(const sp_conv_params& p, int prio, hipStream_t s) {
     }
     const int cotiles = (p.cout + G::CO_T - 1) / G::CO_T;
     const int total = p.n * (p.h / TH) * (p.w_ / G::TW) * cotiles;
-    int grid = total < PP_NUM_CU ? total : PP_NUM_CU;       // persistent: one block per CU
-    if (grid >= 8) grid -= grid % 8;
+    // persistent: one block per CU; the items of a last, partial round split along K where the caller lent the scratch (top of the file)
+    PPSplit sk = pp_split_plan(total, (p.cin_p + G::KC - 1) / G::KC, (!G::F8 && !TIMING && !TAIL && p.workspace != nullptr) ? p.workspace_bytes : 0);
+    const int grid = sk.grid;
     sp_note_route(G::F8 ? "conv3x3_pp<f8,2>" : FW == 1 ? "conv3x3_pp<16bit,2,FAST,w16>" : WCO == 2 ? (FAST ? "conv3x3_pp<16bit,2,FAST>" : "conv3x3_pp<16bit,2>")
                                                                                   : (FAST ? "conv3x3_pp<16bit,1,FAST>" : "conv3x3_pp<16bit,1>"));
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), LDS_BYTES, s, p, cotiles, total, prio);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), LDS_BYTES, s, p, cotiles, total, prio, sk.parts);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }
 
 }  // namespace
+
+// sp_conv2d_workspace(): bytes of fp32 scratch with which a 16-bit 3x3 launch of these dims can split its last round (0: it would not)
+long sp_conv_pp_split_workspace(int n, int h, int w, int cin_p, int cout) {
+    if (h % 8 != 0 || w % PP_TW_WIDE != 0 || cout <= 16) return 0;
+    const int kchunks = (cin_p + 31) / 32;
+    long need = 0;
+    auto plan = [&](long total) {
+        if (total >= (1L << 30)) return;
+        const PPSplit sk = pp_split_plan((int)total, kchunks, 1L << 40);
+        const long b = (long)sk.tail_items * (sk.parts > 1 ? sk.parts - 1 : 0) * PP_SK_SLAB_FLOATS * 4;
+        if (b > need) need = b;
+    };
+    if (cout <= 64) { if (h % 16 == 0) plan((long)n * (h / 16) * (w / PP_TW_WIDE)); }
+    else plan((long)n * (h / 8) * (w / PP_TW_WIDE) * ((cout + 127) / 128));
+    return need;
+}
+
+// the same for the 16-pixel-wide tiles (128 co x 16 x 16 px per item, maps 16 wide)
+long sp_conv_pp_split_workspace_w16(int n, int h, int cin_p, int cout) {
+    if (h % 16 != 0 || cout <= 64 || (long)n * (h / 16) * ((cout + 127) / 128) < 64) return 0;      // (sp_conv_pp_launch's admission)
+    const PPSplit sk = pp_split_plan(n * (h / 16) * ((cout + 127) / 128), (cin_p + 31) / 32, 1L << 40);
+    return (long)sk.tail_items * (sk.parts > 1 ? sk.parts - 1 : 0) * PP_SK_SLAB_FLOATS * 4;
+}
+
+// dispatch(): what a launch of `total` 8-row items costs, in hundredths of the time of one item on every CU - whole rounds without the
+// split; with it the longest piece of the last round plus the hand-over of the partial tiles (pp_split_plan's model)
+long sp_conv_pp_rounds100(long total, int cin_p, long workspace_bytes) {
+    const int kchunks = (cin_p + 31) / 32;
+    if (total < (1L << 30)) {
+        const PPSplit sk = pp_split_plan((int)total, kchunks, workspace_bytes);
+        if (sk.parts > 1 && total >= PP_NUM_CU) return 100 * (total / PP_NUM_CU) + 100 / sk.parts + 162 * (sk.parts - 1) / kchunks + 1;
+    }
+    return 100 * ((total + PP_NUM_CU - 1) / PP_NUM_CU);
+}
 
 // conv_igemm.hip's dispatch(): bf16 3x3 layers with more than 64 output channels on (th x 32)-pixel patches, th = 8 or 16.
 // Returns 1 if the shape is not covered (the caller then keeps its own kernel).

@@ -780,8 +780,9 @@ def _conv_launch(x, w_ptr: int, bias, y, res1, res2, mask_src, slope: float, n, 
     p.n, p.h, p.w_, p.cin_p, p.cout, p.ldy, p.ksize, p.act, p.dtype = n, h, w, cin_p, cout, ldy, ksize, act, sp_dtype(dtype)
     p.pool2, p.in_up2 = int(pool2), (1 if in_up2 else 0)        # pool2: False/0, True/1 = average, 2 = maximum
     ws = None
-    if ksize == 3 and n * h * w <= 8192:
-        # small-spatial 3x3 layers (4x4 .. 16x16): lend the fp32 scratch the kernel asks for to split K across blocks
+    if ksize == 3 and (n * h * w <= 8192 or dtype != torch.float32):
+        # small-spatial 3x3 layers (4x4 .. 16x16): lend the fp32 scratch the kernel asks for to split K across blocks; 16-bit layers on
+        # the ping-pong kernel: the partial tiles of the K-split of its last, partial round of work items (csrc/conv_pp.hip)
         ws_bytes = conv_workspace_bytes(n, h, w, cin_p, cout, ksize, dtype)
         if ws_bytes:
             ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)

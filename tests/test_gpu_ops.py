@@ -239,17 +239,115 @@ def test_conv3x3_pingpong_epilogue_variants_bf16(case):
     y = ops.nhwc_empty(n, cout, ho, ho, dt, "cuda").fill_(-7.0)
     launch(y)
     close(y, ref.cpu(), 8e-3, "ping-pong kernel vs fp32")
-    # (b) bit-identical to the round-2 kernels
+    # (b) bit-identical to the round-2 kernels (without the K-split of the last round, which changes the order of the fp32 sums)
     ops.set_tuning(21, 0)
     try:
         y0 = ops.nhwc_empty(n, cout, ho, ho, dt, "cuda").fill_(3.0)
         launch(y0)
     finally:
         ops.set_tuning(21, -1)
-    for rep in range(3):
-        y1 = ops.nhwc_empty(n, cout, ho, ho, dt, "cuda").fill_(-7.0)
+    ops.set_tuning(TUNE_CONV_PP_SPLIT, 0)
+    try:
+        for rep in range(3):
+            y1 = ops.nhwc_empty(n, cout, ho, ho, dt, "cuda").fill_(-7.0)
+            launch(y1)
+            assert torch.equal(y0, y1), (case, rep, int((y0 != y1).sum()))
+    finally:
+        ops.set_tuning(TUNE_CONV_PP_SPLIT, -1)
+
+
+TUNE_CONV_PP_SPLIT = 28
+PP_SPLIT_CASES = [  # (n, cin, cout, h, w, act, residuals, mask, pool2, input-upsampled, bias, two groups) -> items, tail items R, pieces P
+    (20, 512, 512, 32, 32, 1, 1, False, 0, False, True, False),     # 320 items: R = 64, P = 4 (the metric's 32 x 32 layers)
+    (20, 256, 256, 64, 64, 0, 0, True, 0, False, False, False),     # 640: R = 128, P = 2
+    (40, 512, 512, 32, 32, 0, 2, False, 0, False, True, True),      # 640, two groups
+    (20, 128, 64, 128, 128, 1, 0, False, 0, False, True, False),    # 64 co x 16 x 32 px items: 640
+    (20, 128, 256, 64, 64, 0, 2, False, 1, False, True, False),     # average pooling in the (general) epilogue
+    (20, 64, 128, 64, 64, 2, 0, False, 2, False, True, False),      # maximum pooling; K of two chunks: pieces of one chunk are refused -> unsplit
+    (20, 256, 128, 64, 64, 0, 0, True, 0, True, False, False),      # pooled-gradient input: 320
+    (33, 136, 128, 64, 64, 1, 0, False, 0, False, True, False),     # 528: R = 16, five chunks (partial last chunk) -> P = 2
+    (10, 520, 320, 64, 64, 0, 1, False, 0, False, True, False),     # partial channel tile (320 = 2.5 x 128), 17 chunks: 480 items, R = 224 -> unsplit
+    (9, 200, 384, 32, 64, 3, 0, False, 0, False, True, False),      # tanh (general epilogue), 9 x 4 x 2 x 3 = 216 items < 256 -> unsplit
+    (11, 264, 384, 32, 64, 1, 0, False, 0, False, True, False),     # 264 items: R = 8, P = 4 of nine chunks (2, 2, 2, 3)
+    # less than one round: every item is a tail item, the grid is items x pieces
+    (4, 256, 256, 64, 64, 1, 1, False, 0, False, True, False),      # 128 items x 2
+    (20, 512, 512, 16, 16, 1, 0, True, 0, False, True, False),      # 128 co x 16 x 16 px items: 80 x 3 (the metric's 16 x 16 layers)
+    (20, 520, 512, 16, 16, 0, 2, False, 0, False, True, True),      # ... partial last chunk, two groups
+    (3, 96, 128, 32, 64, 1, 0, False, 0, False, True, False),       # 24 items x 3 of three chunks?  no: pieces of one chunk are refused -> unsplit
+    (3, 160, 128, 32, 64, 1, 0, False, 0, False, True, False),      # 24 items, five chunks: x 2
+]
+
+
+@pytest.mark.parametrize("case", PP_SPLIT_CASES)
+def test_conv3x3_pingpong_tail_split_bf16(case):
+    """conv_pp.hip's K-split of the last, partial round of work items (round 6): launches whose item count leaves a remainder over the
+    256 persistent blocks - the metric's batch of 20 puts most mid-network layers there.  (a) against fp32 arithmetic on the same
+    bf16 operands; (b) against the unsplit launch (SP_TUNE_CONV_PP_SPLIT = 0): the same values up to the order of the fp32 partial sums;
+    (c) five launches into dirty outputs are bit-identical (pieces are added in a fixed order; the counters are clean after every
+    launch), interleaved with an unrelated launch that reuses counters and scratch."""
+    n, cin, cout, h, w_, act, res, mask, pool2, up, bias, groups = case
+    dt = torch.bfloat16
+    g = torch.Generator(device="cuda").manual_seed(23)
+    ho, wo = (h // 2, w_ // 2) if pool2 else (h, w_)
+    hin, win = (h // 2, w_ // 2) if up else (h, w_)
+    x = ops.nhwc_empty(n, cin, hin, win, dt, "cuda").normal_(generator=g)
+    w = (torch.randn(cout, 3, 3, cin, device="cuda", generator=g) * 0.05).to(dt)
+    b = torch.randn(cout, device="cuda", generator=g) if bias else None
+    mk = lambda: ops.nhwc_empty(n, cout, ho, wo, dt, "cuda").normal_(generator=g)
+    r1 = mk() if res >= 1 else None
+    r2 = mk() if res >= 2 else None
+    ms = mk() if mask else None
+    split = n // 2
+    scales = torch.tensor([1.0, 0.8125], device="cuda") if groups else None
+
+    def launch(y):
+        ops._conv_launch(x, w.data_ptr(), b, y, r1, r2, ms, 0.2, n, h, w_, cin, cout, cout, 3, act, dt, pool2, up,
+                         img_scale=scales.data_ptr() if groups else 0, img_split=split if groups else 0)
+
+    xin = x.float()
+    if up:
+        xin = 0.25 * F.interpolate(xin, scale_factor=2, mode="nearest")
+    ref = F.conv2d(xin, w.float().permute(0, 3, 1, 2), None, padding=1)
+    if groups:
+        ref[split:] *= 0.8125
+    if b is not None:
+        ref = ref + b.view(1, -1, 1, 1)
+    if pool2 == 1:
+        ref = F.avg_pool2d(ref, 2)
+    elif pool2 == 2:
+        ref = F.max_pool2d(ref, 2)
+    if ms is not None:
+        ref = ref * torch.where(ms.float() > 0, 1.0, 0.2)
+    if r1 is not None:
+        ref = ref + r1.float()
+    if r2 is not None:
+        ref = ref + r2.float()
+    ref = {0: lambda t: t, 1: lambda t: F.leaky_relu(t, 0.2), 2: F.relu, 3: torch.tanh}[act](ref)
+    ops.set_tuning(TUNE_CONV_PP_SPLIT, 0)
+    try:
+        y0 = ops.nhwc_empty(n, cout, ho, wo, dt, "cuda").fill_(3.0)
+        launch(y0)
+    finally:
+        ops.set_tuning(TUNE_CONV_PP_SPLIT, -1)
+    close(y0, ref.cpu(), 8e-3, "unsplit launch vs fp32")
+    # an unrelated split launch between the repetitions: it shares the counters and (through the allocator) the scratch
+    xo = ops.nhwc_empty(20, 64, 32, 32, dt, "cuda").normal_(generator=g)
+    wo_ = (torch.randn(512, 3, 3, 64, device="cuda", generator=g) * 0.05).to(dt)
+    yo = ops.nhwc_empty(20, 512, 32, 32, dt, "cuda")
+    first = None
+    for rep in range(5):
+        y1 = ops.nhwc_empty(n, cout, ho, wo, dt, "cuda").fill_(-7.0)
         launch(y1)
-        assert torch.equal(y0, y1), (case, rep, int((y0 != y1).sum()))
+        ops._conv_launch(xo, wo_.data_ptr(), None, yo, None, None, None, 0.2, 20, 32, 32, 64, 512, 512, 3, 0, dt, 0, False)
+        if first is None:
+            first = y1
+            close(y1, ref.cpu(), 8e-3, "split launch vs fp32")
+            d = (y1.float() - y0.float()).abs()
+            # same products, other order of the fp32 sums: at most one bf16 rounding step apart, and rarely
+            assert float((d / (y0.float().abs() + 1.0)).max()) <= 2.0 ** -7, float(d.max())
+            assert float((d > 0).float().mean()) < 0.05, float((d > 0).float().mean())
+        else:
+            assert torch.equal(first, y1), (case, rep, int((first != y1).sum()))
 
 
 PPW_CASES = [  # (n, cin, cout, h, w, act, residuals, mask, input-upsampled, bias, two groups, pool2)
