@@ -118,10 +118,20 @@ def test_bank_flat_layout_covers_every_parameter_once():
         assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))                       # no overlap
         assert spans[0][0] >= bank.flat.data_ptr() and spans[-1][1] <= bank.flat.data_ptr() + 4 * bank.flat_floats
         assert [g[0] for g in bank.group_range[1:]] == [g[1] for g in bank.group_range[:-1]] and bank.group_range[0][0] == 0
-        ranges = bank.flat_ranges(1 << 18)
+        ranges = bank.flat_ranges(1 << 18, min_floats=0)
         assert ranges[0][0] == bank.group_range[-1][0]                                    # the last group leads
         cov = sorted(ranges)
         assert cov[0][0] == 0 and cov[-1][1] == bank.flat_floats and all(x[1] == y[0] for x, y in zip(cov, cov[1:]))
+        # no collective below the minimum (default 8 MB) unless the buffer itself is smaller: short spans join their neighbours
+        for min_floats in (1 << 16, 1 << 18, 1 << 30):
+            ranges = bank.flat_ranges(1 << 19, min_floats=min_floats)
+            cov = sorted(ranges)
+            assert cov[0][0] == 0 and cov[-1][1] == bank.flat_floats and all(x[1] == y[0] for x, y in zip(cov, cov[1:]))
+            tail = (bank.sn_floats, bank.flat_floats)
+            assert len(ranges) <= 2 or all(b - a >= min_floats for a, b in ranges if (a, b) != tail), (min_floats, ranges)
+            lead = [r for r in ranges if r[0] == ranges[0][0] or r[0] > ranges[0][0]]
+            assert ranges[0][0] > 0 or len(ranges) <= 2, ranges                                           # the late layers still lead
+            assert max(b for _, b in lead) in (bank.sn_floats, bank.flat_floats), ranges
 
 
 def test_bank_rebuild_keeps_the_flat_gradient_buffer():

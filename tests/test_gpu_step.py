@@ -143,13 +143,17 @@ def bf16_step_errors(tag, graphed=False):
 # the storage noise.  A GPU run is one realisation of that noise, the model another (other rounding points: the kernels fuse
 # activation / residual / pooling into one rounding where the model rounds after every primitive), and the worst of 4096 pixels
 # is a tail statistic: the bound is NOISE_FACTOR x the model's figure, computed at test time.
-NOISE_FACTOR = 2.0
+# Round 6 (round-5 VERDICT, next #8): the factor was a flat 2.0; now per statistic = the largest measured / model ratio of every
+# recorded run (rounds 3 - 6, five boxes; the step is deterministic up to the order of a few fp32 atomics, so boxes agree to the last
+# digits printed) + 20 %: losses 1.57 (cf=4: 1.40e-3 vs 8.9e-4 - a mean over 4 x 4 x 128 predictions, few effective samples),
+# worst pixel 1.23 (round 4, cf=1), pixel rms 0.95.
+NOISE_FACTOR = {"loss_rel": 1.9, "pixel_max": 1.5, "pixel_rms": 1.15}
 
 
 def assert_within_storage_noise(rec, model, what):
     for key in ("loss_rel", "pixel_max", "pixel_rms"):
-        got, allowed = max(rec[key]), NOISE_FACTOR * max(model[key])
-        assert got <= allowed, "%s: %s %.3e > %.1f x the oracle's storage-noise model %.3e" % (what, key, got, NOISE_FACTOR, max(model[key]))
+        got, allowed = max(rec[key]), NOISE_FACTOR[key] * max(model[key])
+        assert got <= allowed, "%s: %s %.3e > %.2f x the oracle's storage-noise model %.3e" % (what, key, got, NOISE_FACTOR[key], max(model[key]))
 
 
 @pytest.mark.parametrize("tag", ["step_cf1_b2_seed0", "step_cf4_b4_seed1"])
