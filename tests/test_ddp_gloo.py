@@ -124,7 +124,7 @@ def test_bank_flat_layout_covers_every_parameter_once():
         assert cov[0][0] == 0 and cov[-1][1] == bank.flat_floats and all(x[1] == y[0] for x, y in zip(cov, cov[1:]))
         # no collective below the minimum (default 8 MB) unless the buffer itself is smaller: short spans join their neighbours
         for min_floats in (1 << 16, 1 << 18, 1 << 30):
-            ranges = bank.flat_ranges(1 << 19, min_floats=min_floats)
+            ranges = bank.flat_ranges(max(1 << 19, min_floats), min_floats=min_floats)
             cov = sorted(ranges)
             assert cov[0][0] == 0 and cov[-1][1] == bank.flat_floats and all(x[1] == y[0] for x, y in zip(cov, cov[1:]))
             tail = (bank.sn_floats, bank.flat_floats)
