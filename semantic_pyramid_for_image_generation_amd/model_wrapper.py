@@ -148,7 +148,9 @@ class ModelWrapper(object):
             return
         fired = self._fired if eager else set()
         todo = []
-        for a, b in bank.flat_ranges(max(1, red.bucket_bytes // 4)):
+        # replayed graphs: the whole buffer is final here - no collective below 8 MB (SpectralNormBank.flat_ranges); eager launches: the
+        # groups have handed their own ranges over from inside the backward pass, what is left is matched against them group by group
+        for a, b in bank.flat_ranges(max(1, red.bucket_bytes // 4), **({"min_floats": 0} if eager else {})):
             if not any(fa <= a and b <= fb for fa, fb in fired):
                 todo.append((a, b))
         red.reduce_flat(bank.flat, todo)
