@@ -447,20 +447,36 @@ def test_vgg_pass_with_gradient_without_the_unpooled_tensors(pair, dtype):
     b = (torch.rand(2, 3, 256, 256, generator=g) * 2 - 1).cuda()
     results = []
     saved = models._VGG_POOL_IDX
+
+    def run(on):
+        models._VGG_POOL_IDX = on
+        x = a.clone().requires_grad_(True)
+        feats = V.forward_pair(x, b)[0] if pair else V(x)
+        seeds = [torch.randn(f.shape, generator=torch.Generator().manual_seed(10 + i)).cuda().to(f.dtype) for i, f in enumerate(feats)]
+        torch.autograd.backward(feats, seeds)
+        return [f.detach().clone() for f in feats], x.grad.clone()
     try:
-        for on in (False, True):
-            models._VGG_POOL_IDX = on
-            x = a.clone().requires_grad_(True)
-            feats = V.forward_pair(x, b)[0] if pair else V(x)
-            seeds = [torch.randn(f.shape, generator=torch.Generator().manual_seed(10 + i)).cuda().to(f.dtype) for i, f in enumerate(feats)]
-            torch.autograd.backward(feats, seeds)
-            results.append(([f.detach().clone() for f in feats], x.grad.clone()))
+        # bit-identity is a statement about the two epilogue forms on the SAME schedule of fp32 sums: the K-split of a launch's last
+        # partial round (csrc/conv_pp.hip, round 6) depends on the item count, which the two forms do not share (one launch over both
+        # groups vs one per group) - it is switched off for this comparison and checked for closeness below
+        ops.set_tuning(28, 0)
+        try:
+            for on in (False, True):
+                results.append(run(on))
+        finally:
+            ops.set_tuning(28, -1)
+        split_on = run(True)
     finally:
         models._VGG_POOL_IDX = saved
     (f0, g0), (f1, g1) = results
     for i, (u, v) in enumerate(zip(f0, f1)):
         assert torch.equal(u, v), ("feature", i)
     assert torch.equal(g0, g1) and float(g0.abs().max()) > 0
+    for i, (u, v) in enumerate(zip(f1, split_on[0])):
+        d = (u.float() - v.float()).abs()
+        assert float(d.max()) <= 2.0 ** -6 * max(float(u.float().abs().max()), 1.0), ("feature with the K-split", i, float(d.max()))
+    dg = (g1.float() - split_on[1].float()).abs()
+    assert float(dg.max()) <= 2e-2 * float(g1.float().abs().max()), float(dg.max())
 
 
 def test_train_step_with_the_next_batch_announced_matches_plain_steps():
