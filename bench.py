@@ -44,7 +44,7 @@ PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "f32": 157.3}      # dense MFMA p
 TORCH_DTYPE = {"bf16": torch.bfloat16, "fp16": torch.float16, "f32": torch.float32}
 DOMINANT_KERNEL = "conv3x3_pp_kernel<bf16,2> (sp_conv2d_igemm, 3x3, Cout>64, 128 co x 8x32 px tiles, ping-pong schedule)"
 DOMINANT_KERNEL_SYMBOL = r"conv3x3_pp_kernel<bf16, 2, [^>]*, 2(, false)?(, (false|true))?>\("      # regex: every epilogue form on 32-wide tiles (not the 16-wide form; optional trailing arguments: round 4's fused-tail flag - off - and round 5's window-position flag)
-TRAFFIC_FILES = ("round5_hbm_traffic_per_kernel.json", "round4_hbm_traffic_per_kernel.json", "round3_hbm_traffic_per_kernel.json", "round2_hbm_traffic_per_kernel.json")
+TRAFFIC_FILES = ("round6_hbm_traffic_per_kernel.json", "round5_hbm_traffic_per_kernel.json", "round4_hbm_traffic_per_kernel.json", "round3_hbm_traffic_per_kernel.json", "round2_hbm_traffic_per_kernel.json")
 
 
 def parse():
