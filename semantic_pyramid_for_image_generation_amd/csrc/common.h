@@ -179,6 +179,8 @@ long sp_conv_pp_split_workspace(int n, int h, int w, int cin_p, int cout);   // 
 long sp_conv_pp_split_workspace_w16(int n, int h, int cin_p, int cout);      // ... of its 16-pixel-wide tiles
 long sp_conv_pp_rounds100(long total, int cin_p, long workspace_bytes);      // ... and what a launch of `total` 8-row items costs with it
 int sp_conv_ppw_launch(const sp_conv_params& p, hipStream_t s);      // conv_ppw.hip: 128 co x 16 x 32 px, 64 co x 4 rows per wave
+long sp_conv_ppw_split_workspace(int n, int h, int w, int cin_p, int cout);   // conv_ppw.hip: scratch of ITS K-split of the last partial round
+long sp_conv_ppw_rounds100(long total, int cin_p, long workspace_bytes);      // ... and the cost of `total` 16-row items with it
 int sp_conv_ppw_covers(const sp_conv_params& p);                    // ... whether it takes the launch at all (shape, epilogue)
 // reduce_queue.hip (compiled once, shared by both flavours): true = the slab reduction was queued for sp_wgrad_reduce_flush
 bool spq_push_reduce(const float* slabs, int nsplit, long n_dw, float* dw, const float* bias_slabs, int bias_ld, int cout, float* dbias);

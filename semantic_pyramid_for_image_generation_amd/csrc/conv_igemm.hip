@@ -1608,8 +1608,10 @@ int dispatch(const sp_conv_params& p, hipStream_t s) {
                 const int kch = (p.cin_p + 31) / 32;
                 const long ratio = kch >= 12 ? 172 : kch >= 6 ? 185 : kch >= 3 ? 194 : 204;
                 // (the 8-row form splits the items of a last, partial round along K - conv_pp.hip: its cost is no longer whole rounds)
-                const long rh100 = sp_conv_pp_rounds100(2 * bt, p.cin_p, p.workspace != nullptr ? p.workspace_bytes : 0);
-                if (ppw_mode == 2 || ratio * rt < rh100) {
+                const long wsb = p.workspace != nullptr ? p.workspace_bytes : 0;
+                const long rh100 = sp_conv_pp_rounds100(2 * bt, p.cin_p, wsb);
+                const long rt100 = sp_conv_ppw_rounds100(bt, p.cin_p, wsb);       // (the 16-row form splits its last round too)
+                if (ppw_mode == 2 || ratio * rt100 < 100 * rh100) {
                     const int rc = sp_conv_ppw_launch(p, s);
                     if (rc != 1) return rc;
                 }
@@ -1680,7 +1682,8 @@ extern "C" int sp_conv2d_workspace(int32_t n, int32_t h, int32_t w_, int32_t cin
     const bool halo_path = ksize == 3 && cout > 32 && h % HALO_TH == 0 && w_ % HALO_TW == 0;
     if (halo_path && dtype != SP_F32 && sp_tune(SP_TUNE_CONV_PP, 1)) {
         // the ping-pong kernel's K-split of its last partial round (conv_pp.hip): partial tiles of the tail items
-        *bytes_out = sp_conv_pp_split_workspace(n, h, w_, cin_p, cout);
+        const long b8 = sp_conv_pp_split_workspace(n, h, w_, cin_p, cout), b16 = sp_conv_ppw_split_workspace(n, h, w_, cin_p, cout);
+        *bytes_out = b8 > b16 ? b8 : b16;
         return SP_OK;
     }
     if (ksize == 3 && w_ == 16 && cout > 64 && dtype != SP_F32 && (sp_tune(SP_TUNE_CONV_PP, 1) == 1 || sp_tune(SP_TUNE_CONV_PP, 1) == 3)) {

@@ -502,12 +502,13 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
                         const float* src = slab0 + (long)q * PP_SK_SLAB_FLOATS;
                         // all 64 loads of a slab in flight: one round trip to the memory side per slab (the stage's fragment registers are
                         // free here; two trips of 32 cost the owner of a four-piece item 12 us)
-                        float t[NFR * 16];
+                        f32x4_t t[4 * NFR];                              // whole fragments: the accumulators are 4-register tuples (element-wise
+                                                                         // updates cost conv_ppw.hip, with its 128 accumulators, 300 spilled registers)
 #pragma unroll
                         for (int k = 0; k < NFR * 16; ++k)
-                            t[k] = __hip_atomic_load(src + k * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            t[k >> 2][k & 3] = __hip_atomic_load(src + k * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-                        for (int k = 0; k < NFR * 16; ++k) acc[k / (NFR * 4)][(k >> 2) % NFR][k & 3] += t[k];
+                        for (int f = 0; f < 4 * NFR; ++f) acc[f / NFR][f % NFR] += t[f];
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     if (lane == 0) __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next launch

@@ -32,6 +32,36 @@ namespace {
 constexpr int PW_NUM_CU = 256;
 constexpr int PW_BIAS_MAX = 1024;
 
+// ---- K-split of the last, partial round of work items: conv_pp.hip's scheme ("tail split", top of that file) on this kernel's items.
+// A piece is 8 waves x 64 lanes x 128 accumulator registers = 256 KB of fp32; an item takes ~1.8 x an 8-row item of conv_pp.hip
+// (6.7 us per 32-channel chunk), a piece handed over ~1.5 x (twice the bytes, the same latency chain).
+constexpr int PW_SK_MAX_PARTS = 4;
+constexpr int PW_SK_SLAB_FLOATS = 8 * 64 * 128;
+__device__ int g_pw_sk_flags[PW_NUM_CU * 8];
+
+struct PWSplit { int parts, tail_items, grid; };
+inline PWSplit pw_split_plan(int total, int kchunks, long workspace_bytes) {
+    PWSplit r{0, 0, total < PW_NUM_CU ? total : PW_NUM_CU};
+    if (r.grid >= 8) r.grid -= r.grid % 8;
+    const int mode = sp_tune(SP_TUNE_CONV_PP_SPLIT, 1);
+    if (!mode || total <= 0 || (total < PW_NUM_CU && mode == 2)) return r;
+    const int R = total % PW_NUM_CU;
+    if (R == 0) return r;
+    int pmax = PW_NUM_CU / R;
+    if (pmax > PW_SK_MAX_PARTS) pmax = PW_SK_MAX_PARTS;
+    int P = 1;
+    long best = 67L * kchunks;
+    const long handover = total >= 2 * PW_NUM_CU ? 60 : 90;
+    for (int q = 2; q <= pmax && kchunks / q >= 2; ++q) {
+        const long c = 67L * ((kchunks + q - 1) / q) + handover * (q - 1);
+        if (c < best && 20 * c < 19 * 67L * kchunks) { best = c; P = q; }
+    }
+    if (P < 2 || (long)R * (P - 1) * PW_SK_SLAB_FLOATS * 4 > workspace_bytes) return r;
+    r.parts = P; r.tail_items = R;
+    r.grid = total < PW_NUM_CU ? R * P : PW_NUM_CU;
+    return r;
+}
+
 template <typename T>
 struct PWGeom {
     static constexpr int E = 16 / (int)sizeof(T), KC = 4 * E;
@@ -48,7 +78,7 @@ struct PWGeom {
 };
 
 template <typename T, bool TIMING = false, bool DMA_LB = true, bool POOL = false>
-__global__ __launch_bounds__(512) void conv3x3_ppw_kernel(sp_conv_params p, int cotiles, int total, int prio) {
+__global__ __launch_bounds__(512) void conv3x3_ppw_kernel(sp_conv_params p, int cotiles, int total, int prio, int sk_parts) {
     static_assert(sizeof(T) == 2, "16-bit storage");
     using G = PWGeom<T>;
     constexpr int E = G::E, KC = G::KC, CO_T = G::CO_T, WPX = G::WPX, RW = G::RW, FW = G::FW, NB = G::NB, NFR = G::NFR, HR = G::HR, HP = G::HP, TH = G::TH;
@@ -69,8 +99,20 @@ __global__ __launch_bounds__(512) void conv3x3_ppw_kernel(sp_conv_params p, int 
     const int GR = gridDim.x;
     int bid = blockIdx.x;
     if ((GR & 7) == 0) bid = (bid & 7) * (GR >> 3) + (bid >> 3);
-    const int my_items = (total - bid + GR - 1) / GR;
-    const int nchunks = my_items * kchunks;
+    // tail split (conv_pp.hip): the first full_total items go round robin, the rest in K pieces
+    const int full_total = sk_parts > 1 ? (total / GR) * GR : total;
+    const int my_items = (full_total - bid + GR - 1) / GR;
+    int t_item = -1, t_part = 0, t_k0 = 0, t_k1 = 0, t_j = 0;
+    if (sk_parts > 1 && (int)blockIdx.x < (total - full_total) * sk_parts) {
+        t_j = (int)blockIdx.x / sk_parts;
+        t_part = (int)blockIdx.x - t_j * sk_parts;
+        t_item = full_total + t_j;
+        t_k0 = t_part * kchunks / sk_parts;
+        t_k1 = (t_part + 1) * kchunks / sk_parts;
+    }
+    const bool has_tail = t_item >= 0;
+    const bool t_owner = t_part == sk_parts - 1;
+    const int nchunks = my_items * kchunks + (has_tail ? t_k1 - t_k0 : 0);
     if (nchunks <= 0) return;
 
     // ---- bias -> LDS (fp32, zero padded to whole co-tiles), before the first LDS-DMA is in flight
@@ -96,10 +138,14 @@ __global__ __launch_bounds__(512) void conv3x3_ppw_kernel(sp_conv_params p, int 
     const int ls = ((lane & 3) ^ ((lane >> 3) & 3)) * E;   // halo: logical slot (elements) this lane fetches, key (hp >> 1) & 3
     unsigned h_off[HPW], w_off[W_PER];
     struct Coords { int co_i, tx_i, ty_i, n; };
-    Coords cur, nxt;
+    Coords cur, nxt, tailc;
     int s_co, s_tx, s_ty, s_n;
     {
-        int t = bid;
+        int t = has_tail ? t_item : 0;
+        tailc.co_i = t % cotiles; t /= cotiles;
+        tailc.tx_i = t % tiles_x; t /= tiles_x;
+        tailc.ty_i = t % tiles_y; tailc.n = t / tiles_y;
+        t = bid;
         cur.co_i = t % cotiles; t /= cotiles;
         cur.tx_i = t % tiles_x; t /= tiles_x;
         cur.ty_i = t % tiles_y; cur.n = t / tiles_y;
@@ -116,7 +162,20 @@ __global__ __launch_bounds__(512) void conv3x3_ppw_kernel(sp_conv_params p, int 
         r.n = c.n + s_n + cy;
         return r;
     };
-    nxt = advance(cur);
+    int it = 0;
+    const int t_pos = has_tail ? (t_owner ? my_items : 0) : -1;     // a contributing piece leads its block, the owning piece closes it
+    Coords strided = cur;
+    auto item_coords = [&](int idx, bool& is_tail) {
+        is_tail = idx == t_pos;
+        if (is_tail) return tailc;
+        const Coords c = strided;
+        strided = advance(strided);
+        return c;
+    };
+    bool cur_is_tail, nxt_is_tail;
+    cur = item_coords(0, cur_is_tail);
+    nxt = item_coords(1, nxt_is_tail);
+    bool sk_signal_due = false;
     auto set_halo_desc = [&](const Coords& c) {
         const int n = c.n, ty0 = c.ty_i * TH, tx0 = c.tx_i * PW_TW;
         int l4 = lane >> 2;
@@ -187,17 +246,19 @@ __global__ __launch_bounds__(512) void conv3x3_ppw_kernel(sp_conv_params p, int 
     // ---- prologue: chunk 0's halo, weight stages 0 .. LA - 1
     set_halo_desc(cur);
     set_w_desc(cur);
+    int kc = cur_is_tail ? t_k0 : 0;
+    int kc_end = cur_is_tail ? t_k1 : kchunks;
 #pragma unroll
-    for (int i = 0; i < HPW; ++i) issue_halo_piece(i, true, 0, 0);
+    for (int i = 0; i < HPW; ++i) issue_halo_piece(i, true, kc * KC, 0);
 #pragma unroll
     for (int ds = 0; ds < LA; ++ds)
 #pragma unroll
-        for (int i = 0; i < W_PER; ++i) issue_w_piece(i, true, 0, ds, ds);
+        for (int i = 0; i < W_PER; ++i) issue_w_piece(i, true, kc * KC, ds, ds);
     wait_vmcnt<(LA - 1) * W_PER>();                         // halo 0 and stage 0 landed (this wave's pieces); stage 1 may fly
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the bias copy
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    bias_fetch(true, cur.co_i * CO_T);
+    bias_fetch(!(cur_is_tail && !t_owner), cur.co_i * CO_T);
     auto acc_from_bias = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -220,12 +281,11 @@ __global__ __launch_bounds__(512) void conv3x3_ppw_kernel(sp_conv_params p, int 
     };
     if constexpr (TIMING) tprev = __builtin_readcyclecounter();
     int g3 = 0;                                             // weight ring slot of the stage being computed (stage index mod 3)
-    int kc = 0;
     for (int gc = 0; gc < nchunks; ++gc) {
         const bool more_chunks = gc + 1 < nchunks;
-        const bool item_ends = kc + 1 == kchunks;
+        const bool item_ends = kc + 1 == kc_end;
         const unsigned hb = (unsigned)((gc & 1) * HALO_BUF);
-        const int c0_next = item_ends ? 0 : (kc + 1) * KC;
+        const int c0_next = item_ends ? (nxt_is_tail ? t_k0 * KC : 0) : (kc + 1) * KC;
         auto stage = [&](auto sc) {
             constexpr int st = decltype(sc)::value;        // stage inside the chunk = tap column
             constexpr int TAP_STRIDE = CO_T * 64;
@@ -322,11 +382,68 @@ __global__ __launch_bounds__(512) void conv3x3_ppw_kernel(sp_conv_params p, int 
         stage(std::integral_constant<int, 0>{});
         stage(std::integral_constant<int, 1>{});
         stage(std::integral_constant<int, 2>{});
+        if (sk_signal_due && !item_ends) {                  // first chunk behind a contributing piece: its slab has drained, raise the counter
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(g_pw_sk_flags + t_j * 8 + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sk_signal_due = false;
+        }
         if (item_ends) {
             const int n = cur.n, ty0 = cur.ty_i * TH, tx0 = cur.tx_i * PW_TW, co0 = cur.co_i * CO_T;
             const long pix0 = ((long)n * H + ty0 + RW * wpx) * W + tx0 + (lane & 15);
             const int co_b = co0 + wco * 64 + (lane >> 4) * 16;          // this lane's 16 consecutive channels
             const bool wide = co_b < p.cout;
+            bool run_epilogue = true;
+            if (sk_signal_due) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(g_pw_sk_flags + t_j * 8 + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sk_signal_due = false;
+            }
+            // conv_pp.hip's hand-over on 128 registers per lane.  Written as three separate regions - stores | wait | a loop of loads whose
+            // trip count is zero for everyone but the owner - and sixteen registers per group behind an opaque offset: as one
+            // if / else the two paths (accumulators unchanged / accumulators updated) met in 128 phi copies and the main loop of this
+            // kernel (~245 registers) spilled 300
+            const bool sk_tail = cur_is_tail && sk_parts > 1;           // wave-uniform
+            const bool sk_give = sk_tail && !t_owner, sk_take = sk_tail && t_owner;
+            int woff = wave * 8192 + lane;
+            asm volatile("" : "+v"(woff));                               // (keeps the slab addresses out of the chunk loop's live ranges)
+            float* slab0 = reinterpret_cast<float*>(p.workspace) + ((long)t_j * (sk_parts - 1)) * PW_SK_SLAB_FLOATS + woff;
+            int* flag = g_pw_sk_flags + t_j * 8 + wave;
+            if (sk_give) {
+                float* dst = slab0 + (long)t_part * PW_SK_SLAB_FLOATS;
+                static_for<NFR>([&](auto gc_) {
+                    constexpr int g = decltype(gc_)::value;               // accumulators 16 g .. 16 g + 15 = acc[g / 2][4 (g % 2) .. + 3][0..3]
+                    int o = g * 16 * 64;
+                    asm volatile("" : "+v"(o));
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        __hip_atomic_store(dst + o + k * 64, acc[g / 2][4 * (g % 2) + (k >> 2)][k & 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                sk_signal_due = true;
+                run_epilogue = false;
+            }
+            if (sk_take) {
+                while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sk_parts - 1) __builtin_amdgcn_s_sleep(8);
+                asm volatile("" ::: "memory");
+            }
+            const int sk_slabs = sk_take ? sk_parts - 1 : 0;
+#pragma unroll 1
+            for (int q = 0; q < sk_slabs; ++q) {
+                const float* src = slab0 + (long)q * PW_SK_SLAB_FLOATS;
+                static_for<NFR>([&](auto gc_) {
+                    constexpr int g = decltype(gc_)::value;
+                    int o = g * 16 * 64;
+                    asm volatile("" : "+v"(o));
+                    f32x4_t t[4];                                        // whole fragments: the accumulators are 4-register tuples
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) t[k >> 2][k & 3] = __hip_atomic_load(src + o + k * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) acc[g / 2][4 * (g % 2) + f] += t[f];
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
+            if (sk_take && lane == 0) __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (run_epilogue) {
             if (up) {                                                    // the 1/4 of the average-pooling gradient
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -432,10 +549,14 @@ __global__ __launch_bounds__(512) void conv3x3_ppw_kernel(sp_conv_params p, int 
                 });
             }
             }
-            kc = 0;
+            }                                               // run_epilogue
+            ++it;
             cur = nxt;
-            nxt = advance(nxt);
-            bias_fetch(more_chunks, cur.co_i * CO_T);
+            cur_is_tail = nxt_is_tail;
+            kc = cur_is_tail ? t_k0 : 0;
+            kc_end = cur_is_tail ? t_k1 : kchunks;
+            nxt = item_coords(it + 1, nxt_is_tail);
+            bias_fetch(more_chunks && !(cur_is_tail && !t_owner), cur.co_i * CO_T);
             acc_from_bias();
             stamp(5);
             if (half_b) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
@@ -444,6 +565,10 @@ __global__ __launch_bounds__(512) void conv3x3_ppw_kernel(sp_conv_params p, int 
         }
     }
     if (!half_b) __builtin_amdgcn_s_barrier();              // the barrier the other half passes after its last MFMA segment
+    if (sk_signal_due) {                                    // (a contributing piece with no item behind it)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(g_pw_sk_flags + t_j * 8 + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if constexpr (TIMING) {
         if (lane == 0 && p.workspace != nullptr) {
             float* out = reinterpret_cast<float*>(p.workspace) + ((long)blockIdx.x * 8 + wave) * 16;
@@ -465,10 +590,10 @@ int launch_ppw(const sp_conv_params& p, int prio, hipStream_t s) {
     }
     const int cotiles = (p.cout + G::CO_T - 1) / G::CO_T;
     const int total = p.n * (p.h / G::TH) * (p.w_ / G::TW) * cotiles;
-    int grid = total < PW_NUM_CU ? total : PW_NUM_CU;       // persistent: one block per CU
-    if (grid >= 8) grid -= grid % 8;
+    // persistent: one block per CU; the items of a last, partial round split along K where the caller lent the scratch
+    const PWSplit sk = pw_split_plan(total, (p.cin_p + G::KC - 1) / G::KC, (!TIMING && p.workspace != nullptr) ? p.workspace_bytes : 0);
     sp_note_route("conv3x3_ppw<16bit> (64 co x 4 rows per wave)");
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), G::LDS, s, p, cotiles, total, prio);
+    hipLaunchKernelGGL(kern, dim3((unsigned)sk.grid), dim3(512), G::LDS, s, p, cotiles, total, prio, sk.parts);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }
@@ -482,6 +607,26 @@ int sp_conv_ppw_covers(const sp_conv_params& p) {
     if (p.h % 16 != 0 || p.w_ % 32 != 0) return 0;
     if ((long)p.n * p.h * p.w_ * p.cin_p * 2 >= (1L << 30) || (long)p.cout * 9 * p.cin_p * 2 >= (1L << 30)) return 0;
     return !((p.cout & 15) != 0 || (p.ldy & 7) != 0 || p.act == SP_ACT_TANH || p.tail_w != nullptr || p.pool_idx != nullptr || p.y == nullptr);
+}
+
+// sp_conv2d_workspace(): scratch for this kernel's K-split (0: it would not split / does not cover the dims)
+long sp_conv_ppw_split_workspace(int n, int h, int w, int cin_p, int cout) {
+    if (h % 16 != 0 || w % 32 != 0 || cout <= 64) return 0;
+    const long total = (long)n * (h / 16) * (w / 32) * ((cout + 127) / 128);
+    if (total >= (1L << 30)) return 0;
+    const PWSplit sk = pw_split_plan((int)total, (cin_p + 31) / 32, 1L << 40);
+    return (long)sk.tail_items * (sk.parts > 1 ? sk.parts - 1 : 0) * PW_SK_SLAB_FLOATS * 4;
+}
+
+// dispatch(): cost of `total` 16-row items in hundredths of ONE item's time on every CU (whole rounds without the split)
+long sp_conv_ppw_rounds100(long total, int cin_p, long workspace_bytes) {
+    const int kchunks = (cin_p + 31) / 32;
+    if (total < (1L << 30)) {
+        const PWSplit sk = pw_split_plan((int)total, kchunks, workspace_bytes);
+        if (sk.parts > 1 && total >= PW_NUM_CU)
+            return 100 * (total / PW_NUM_CU) + 100 * ((kchunks + sk.parts - 1) / sk.parts) / kchunks + 100 * (total >= 2 * PW_NUM_CU ? 60 : 90) * (sk.parts - 1) / (67 * kchunks) + 1;
+    }
+    return 100 * ((total + PW_NUM_CU - 1) / PW_NUM_CU);
 }
 
 int sp_conv_ppw_launch(const sp_conv_params& p, hipStream_t s) {

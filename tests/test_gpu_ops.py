@@ -280,6 +280,33 @@ PP_SPLIT_CASES = [  # (n, cin, cout, h, w, act, residuals, mask, pool2, input-up
 
 @pytest.mark.parametrize("case", PP_SPLIT_CASES)
 def test_conv3x3_pingpong_tail_split_bf16(case):
+    _tail_split_case(case)
+
+
+PPW_SPLIT_CASES = [  # the same for conv_ppw.hip's 16-row items (forced: SP_TUNE_CONV_PPW = 2): (n, cin, cout, h, w, act, res, mask, pool2, up, bias, groups)
+    (20, 256, 256, 64, 64, 1, 1, False, 0, False, True, False),     # 320 items: R = 64
+    (40, 512, 512, 32, 32, 0, 2, False, 0, False, True, True),      # 320, two groups, 16 chunks
+    (40, 256, 128, 64, 64, 0, 0, True, 0, False, False, False),     # 320, mask operand
+    (20, 512, 256, 32, 32, 1, 0, False, 0, False, True, False),     # 80 items: less than a round, x 3
+    (20, 128, 256, 64, 64, 0, 2, False, 1, False, True, False),     # average pooling (the POOL instantiation), 320 items of four chunks
+    (11, 264, 384, 32, 64, 1, 0, False, 0, False, True, False),     # 132 items: no split - partial last chunk, unsplit control
+    (33, 136, 128, 64, 64, 2, 0, False, 2, False, True, False),     # 264 items: R = 8, five chunks, maximum pooling
+    (20, 256, 128, 64, 64, 0, 0, True, 0, True, False, False),      # pooled-gradient input, 160 items: unsplit (R > 128)
+    (36, 192, 128, 64, 64, 1, 0, False, 0, False, True, False),     # 288 items: R = 32, six chunks
+]
+
+
+@pytest.mark.parametrize("case", PPW_SPLIT_CASES)
+def test_conv3x3_ppw_tail_split_bf16(case):
+    """conv_ppw.hip's K-split of the last partial round (256 KB pieces: 128 accumulator registers per lane), forced onto every launch."""
+    ops.set_tuning(26, 2)
+    try:
+        _tail_split_case(case, want_route="conv3x3_ppw")
+    finally:
+        ops.set_tuning(26, -1)
+
+
+def _tail_split_case(case, want_route=None):
     """conv_pp.hip's K-split of the last, partial round of work items (round 6): launches whose item count leaves a remainder over the
     256 persistent blocks - the metric's batch of 20 puts most mid-network layers there.  (a) against fp32 arithmetic on the same
     bf16 operands; (b) against the unsplit launch (SP_TUNE_CONV_PP_SPLIT = 0): the same values up to the order of the fp32 partial sums;
@@ -330,6 +357,8 @@ def test_conv3x3_pingpong_tail_split_bf16(case):
     finally:
         ops.set_tuning(TUNE_CONV_PP_SPLIT, -1)
     close(y0, ref.cpu(), 8e-3, "unsplit launch vs fp32")
+    if want_route is not None:
+        assert L.lib().sp_last_route().decode().startswith(want_route), L.lib().sp_last_route().decode()
     # an unrelated split launch between the repetitions: it shares the counters and (through the allocator) the scratch
     xo = ops.nhwc_empty(20, 64, 32, 32, dt, "cuda").normal_(generator=g)
     wo_ = (torch.randn(512, 3, 3, 64, device="cuda", generator=g) * 0.05).to(dt)
@@ -413,6 +442,7 @@ def test_conv3x3_pingpong_four_row_waves_bf16(case):
     finally:
         ops.set_tuning(21, -1)
     ops.set_tuning(L.TUNE_KEYS["SP_CONV_PPW"], 2)
+    ops.set_tuning(TUNE_CONV_PP_SPLIT, 0)         # (bit-identity is about one order of the fp32 sums: the K-split of the last round has its own test)
     try:
         for rep in range(3):
             y1 = ops.nhwc_empty(n, cout, ho, wo, dt, "cuda").fill_(-7.0)
@@ -423,6 +453,7 @@ def test_conv3x3_pingpong_four_row_waves_bf16(case):
             assert torch.equal(y0, y1), (case, rep, int((y0 != y1).sum()))
     finally:
         ops.set_tuning(L.TUNE_KEYS["SP_CONV_PPW"], -1)
+        ops.set_tuning(TUNE_CONV_PP_SPLIT, -1)
 
 
 @pytest.mark.parametrize("case", [(20, 128, 512, 1, 0, False, True), (16, 520, 512, 0, 2, False, True), (32, 72, 256, 2, 0, True, False),
