@@ -970,9 +970,7 @@ def main():
     if not args.no_kernel_probe:
         try:
             probe = kernel_probe(job.eager_step, peak, steps=5, step_ms=elapsed / args.steps * 1e3)   # the probe brackets individual launches: eager steps
-        except RuntimeError as exc:
-            if world > 1:
-                raise
+        except RuntimeError as exc:          # (raised after the probe's steps have run: the ranks are still in step with each other)
             probe_error = str(exc)
         torch.cuda.synchronize()
         if world > 1:
