@@ -76,7 +76,8 @@ int sp_version(void);
  *   SP_TUNE_IGEMM_TILE       output tile of the LDS-DMA igemm on small-spatial 3x3 layers with Cout > 64: 0 = 64 co x 64 px, 1 = 128 x 128,
  *                            2 = 128 co x 64 px, 3 = 64 co x 128 px; default: 0, or 2 where 64 x 64 tiles make 1 - 2 rounds of the chip and K is long
  *   SP_TUNE_CONV_PPW         16-bit 3x3 layers with Cout > 64 on 16 x 32-pixel patches: the ping-pong kernel with 64 co x 4 rows per wave
- *                            (conv_ppw.hip) where the round count favours 16-row items; 0 = off (tall<2,16> / the 8-row form), 2 = wherever eligible
+ *                            (conv_ppw.hip) where the round count favours 16-row items; 0 = off (tall<2,16> / the 8-row form), 2 = wherever eligible,
+ *                            3 = like 1 with the 16-row form priced WITH the K-split of its last round
  *   SP_TUNE_LINEAR_KS        K range per block of the split-K MFMA linear kernel: 1024 / 512 / 256 / 128 (default: the widest that yields 256 blocks)
  *   SP_TUNE_BN_ITERS         pixels per thread of the elementwise BatchNorm passes (grid sizing; default 2)
  *   SP_TUNE_CONV_PP_SPLIT    0 = the ping-pong 3x3 kernel never splits the work items of its last, partial round along K (default 1: it does

@@ -1610,7 +1610,11 @@ int dispatch(const sp_conv_params& p, hipStream_t s) {
                 // (the 8-row form splits the items of a last, partial round along K - conv_pp.hip: its cost is no longer whole rounds)
                 const long wsb = p.workspace != nullptr ? p.workspace_bytes : 0;
                 const long rh100 = sp_conv_pp_rounds100(2 * bt, p.cin_p, wsb);
-                const long rt100 = sp_conv_ppw_rounds100(bt, p.cin_p, wsb);       // (the 16-row form splits its last round too)
+                // the 16-row form splits its last round too (conv_ppw.hip), but is CHOSEN on whole rounds: priced with its split it
+                // takes a handful of launches the split 8-row form runs within 0 - 6 % of it (256 -> 256 @64^2 x 40: 138 vs 147 us, the
+                // others level) - step-neutral (profiles/round6_ab_ppw_tail_split_step.txt), and ties go to the kernel that is
+                // measured, profiled and tuned as the dominant one.  SP_TUNE_CONV_PPW = 3 prices it with the split.
+                const long rt100 = ppw_mode == 3 ? sp_conv_ppw_rounds100(bt, p.cin_p, wsb) : 100 * rt;
                 if (ppw_mode == 2 || ratio * rt100 < 100 * rh100) {
                     const int rc = sp_conv_ppw_launch(p, s);
                     if (rc != 1) return rc;
