@@ -1084,6 +1084,40 @@ def test_direct_grads_window_matches_autograd_accumulation():
         close(got_new_window[0][n], host(ref[0][n]), 2e-5, "after zero_grad %s" % n, robust=False)
 
 
+def test_non_direct_bank_bias_gradients_with_deferred_reductions_bf16():
+    """Round-5 ADVICE (medium): with the slab reductions of the streaming 1x1 / 8-channel weight-gradient launches deferred to the bank's
+    backward node, a bank WITHOUT direct gradients handed its bias slot back to autograd before the queued reduction had run - autograd
+    then summed the D(real) and D(fake) contributions of an unreduced slot.  16-bit storage (the split path: 256 x 256 maps, thousands
+    of pixels per split), two passes, one backward: every bias and weight gradient of the autograd-accumulated run equals the
+    direct-gradient run (same kernels, same order of the partial sums up to the final addition)."""
+    ops.set_compute_dtype(torch.bfloat16)
+    try:
+        D = models.Discriminator(channel_factor=8).cuda()
+        sd0 = {k: v.clone() for k, v in params.synth_state_dict(D.state_dict(), 3).items()}
+        x1, x2 = rnd(4, 3, 256, 256, seed=1).cuda(), rnd(4, 3, 256, 256, seed=2).cuda()
+        cls = torch.tensor([3, 200, 7, 11]).cuda()
+
+        def run(direct):
+            D.load_state_dict(sd0)
+            D._bank.direct_grads = direct
+            D.zero_grad()
+            loss = ops.sqerr_loss(D(x1, cls), 1.0) + ops.sqerr_loss(D(x2, cls), 0.0)
+            loss.backward()
+            return {n: p.grad.detach().float().clone() for n, p in D.named_parameters() if p.grad is not None}
+        try:
+            ref = run(True)
+            got = run(False)
+        finally:
+            D._bank.direct_grads = False
+        assert set(ref) == set(got)
+        for n in ref:
+            scale = max(float(ref[n].abs().max()), 1e-12)
+            err = float((got[n] - ref[n]).abs().max()) / scale
+            assert err <= 2e-3, (n, err)           # (before the fix: the first layers' biases were off by whole partial sums)
+    finally:
+        ops.set_compute_dtype(torch.float32)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_discriminator_head_and_lsgan(dtype):
     ops.set_compute_dtype(dtype)
