@@ -167,7 +167,14 @@ typedef struct sp_conv_params {
      * routes its gradient) of channel 16 g + c, taken over the values as the storage type holds them - exactly the element
      * sp_maxpool2_bwd would pick from the stored unpooled tensor.  NULL: not recorded. */
     uint32_t* pool_idx;
+    /* Round 6: counters of the 3x3 ping-pong kernels' K-split of their last partial round of work items (conv_pp.hip / conv_ppw.hip).
+     * NULL: the launch never splits.  Otherwise SP_CONV_SPLIT_SYNC_BYTES of device memory that is ZERO when first handed to the
+     * library and is left zero by every launch that used it (the kernels clean up behind themselves): one such area per STREAM
+     * makes concurrent launches on different streams safe - the library keeps no device-side state of its own.  Needs
+     * `workspace` for the partial tiles (sp_conv2d_workspace). */
+    int32_t* split_sync;
 } sp_conv_params;
+#define SP_CONV_SPLIT_SYNC_BYTES 8192
 int sp_conv2d_igemm(const sp_conv_params* p, sp_stream_t stream);
 /* Bytes of fp32 scratch sp_conv2d_igemm wants in sp_conv_params.workspace to split the K loop of this shape over several
  * blocks (3x3 layers of small spatial extent: too few output tiles to fill 256 CUs); 0 = it would not split.  The scratch

@@ -28,6 +28,9 @@ TUNE_KEYS = {"SP_CONV_TALL": 0, "SP_IGEMM_DMA": 1, "SP_WGRAD_ROWS": 2, "SP_DETER
              "SP_CONV_PP": 21, "SP_CONV_PP_PRIO": 22, "SP_WGRAD_PP": 23, "SP_BN_ITERS": 24, "SP_IGEMM_TILE": 25, "SP_CONV_PPW": 26, "SP_LINEAR_KS": 27, "SP_CONV_PP_SPLIT": 28}
 
 
+SP_CONV_SPLIT_SYNC_BYTES = 8192          # include/sempyr.h
+
+
 class SpConvParams(ctypes.Structure):
     _fields_ = [("x", ctypes.c_void_p), ("w", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("y", ctypes.c_void_p),
                 ("res1", ctypes.c_void_p), ("res2", ctypes.c_void_p), ("mask_src", ctypes.c_void_p),
@@ -42,7 +45,7 @@ class SpConvParams(ctypes.Structure):
                 ("split_pix_", ctypes.c_int64),
                 ("tail_w", ctypes.c_void_p), ("tail_bias", ctypes.c_void_p), ("tail_y", ctypes.c_void_p),
                 ("tail_cout", ctypes.c_int32), ("tail_act", ctypes.c_int32), ("tail_ld", ctypes.c_int32), ("reserved2_", ctypes.c_int32),
-                ("pool_idx", ctypes.c_void_p)]
+                ("pool_idx", ctypes.c_void_p), ("split_sync", ctypes.c_void_p)]
 
 
 class SpSnLayer(ctypes.Structure):

@@ -1608,7 +1608,7 @@ int dispatch(const sp_conv_params& p, hipStream_t s) {
                 const int kch = (p.cin_p + 31) / 32;
                 const long ratio = kch >= 12 ? 172 : kch >= 6 ? 185 : kch >= 3 ? 194 : 204;
                 // (the 8-row form splits the items of a last, partial round along K - conv_pp.hip: its cost is no longer whole rounds)
-                const long wsb = p.workspace != nullptr ? p.workspace_bytes : 0;
+                const long wsb = (p.workspace != nullptr && p.split_sync != nullptr) ? p.workspace_bytes : 0;
                 const long rh100 = sp_conv_pp_rounds100(2 * bt, p.cin_p, wsb);
                 // the 16-row form splits its last round too (conv_ppw.hip), but is CHOSEN on whole rounds: priced with its split it
                 // takes a handful of launches the split 8-row form runs within 0 - 6 % of it (256 -> 256 @64^2 x 40: 138 vs 147 us, the

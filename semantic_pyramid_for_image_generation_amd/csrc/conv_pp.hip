@@ -55,10 +55,10 @@ constexpr int PP_BIAS_MAX = 1024;              // output channels whose bias fit
 // version ran every piece last: the owner then waits for store -> signal -> load round trips at the very end of the launch, 10 - 20
 // us, more than the split saves below K = 512.)  Slabs and counters move with agent-scope relaxed atomics (sc1: through the XCD's L2 to
 // the memory side - the L2s of different XCDs are not coherent for plain accesses); the waiter zeroes the counter again, so the
-// counters (a static array, zero at load) are clean whenever no launch is in flight.
+// counters (sp_conv_params.split_sync: the caller's zero-at-rest area, one per stream - the library keeps no device state) are clean
+// whenever no launch is in flight.
 constexpr int PP_SK_MAX_PARTS = 4;
 constexpr int PP_SK_SLAB_FLOATS = 8 * 64 * 64;           // one piece: 8 waves x 64 lanes x 64 accumulator registers = 128 KB
-__device__ int g_pp_sk_flags[PP_NUM_CU * 8];
 
 struct PPSplit { int parts, tail_items, grid; };
 // the plan for `total` items of `kchunks` chunks each; parts <= 1: no split (grid: the unsplit launch's).  total < 256 (less than one
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
             // the first chunk behind a contributing piece: its slab stores were issued three stages ago - raise the counter now (an
             // owner with a single full item in front of its piece asks for it one item after this block started)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_fetch_add(g_pp_sk_flags + t_j * 8 + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_fetch_add(p.split_sync + t_j * 8 + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             sk_signal_due = false;
         }
         if (item_ends) {
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
             bool run_epilogue = true;
             if (sk_signal_due) {                                         // the item behind a contributing piece: its slab has had a whole item to drain
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_fetch_add(g_pp_sk_flags + t_j * 8 + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) __hip_atomic_fetch_add(p.split_sync + t_j * 8 + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 sk_signal_due = false;
             }
             if (cur_is_tail && sk_parts > 1) {                           // wave-uniform
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
                 asm volatile("" : "+v"(woff));                           // (computed HERE: hoisted out of the chunk loop, the sixty-odd
                                                                          // addresses below stay live across it and spill)
                 float* slab0 = reinterpret_cast<float*>(p.workspace) + ((long)t_j * (sk_parts - 1)) * PP_SK_SLAB_FLOATS + woff;
-                int* flag = g_pp_sk_flags + t_j * 8 + wave;
+                int* flag = p.split_sync + t_j * 8 + wave;
                 if (!t_owner) {
                     float* dst = slab0 + (long)t_part * PP_SK_SLAB_FLOATS;
 #pragma unroll
@@ -778,7 +778,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
     if (!half_b) __builtin_amdgcn_s_barrier();              // the barrier the other half passes after its last MFMA segment
     if (sk_signal_due) {                                    // (a contributing piece with no item behind it)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(g_pp_sk_flags + t_j * 8 + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_fetch_add(p.split_sync + t_j * 8 + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if constexpr (G::F8) {
         // one atomic per BLOCK on the running maximum (per item and wave they serialise on one L2 word: 10 K atomics = 100+ us)
@@ -824,7 +824,8 @@ int launch_pp(const sp_conv_params& p, int prio, hipStream_t s) {
     const int cotiles = (p.cout + G::CO_T - 1) / G::CO_T;
     const int total = p.n * (p.h / TH) * (p.w_ / G::TW) * cotiles;
     // persistent: one block per CU; the items of a last, partial round split along K where the caller lent the scratch (top of the file)
-    PPSplit sk = pp_split_plan(total, (p.cin_p + G::KC - 1) / G::KC, (!G::F8 && !TIMING && !TAIL && p.workspace != nullptr) ? p.workspace_bytes : 0);
+    PPSplit sk = pp_split_plan(total, (p.cin_p + G::KC - 1) / G::KC,
+                               (!G::F8 && !TIMING && !TAIL && p.workspace != nullptr && p.split_sync != nullptr) ? p.workspace_bytes : 0);
     const int grid = sk.grid;
     sp_note_route(G::F8 ? "conv3x3_pp<f8,2>" : FW == 1 ? "conv3x3_pp<16bit,2,FAST,w16>" : WCO == 2 ? (FAST ? "conv3x3_pp<16bit,2,FAST>" : "conv3x3_pp<16bit,2>")
                                                                                   : (FAST ? "conv3x3_pp<16bit,1,FAST>" : "conv3x3_pp<16bit,1>"));

@@ -37,7 +37,6 @@ constexpr int PW_BIAS_MAX = 1024;
 // (6.7 us per 32-channel chunk), a piece handed over ~1.5 x (twice the bytes, the same latency chain).
 constexpr int PW_SK_MAX_PARTS = 4;
 constexpr int PW_SK_SLAB_FLOATS = 8 * 64 * 128;
-__device__ int g_pw_sk_flags[PW_NUM_CU * 8];
 
 struct PWSplit { int parts, tail_items, grid; };
 inline PWSplit pw_split_plan(int total, int kchunks, long workspace_bytes) {
@@ -384,7 +383,7 @@ __global__ __launch_bounds__(512) void conv3x3_ppw_kernel(sp_conv_params p, int 
         stage(std::integral_constant<int, 2>{});
         if (sk_signal_due && !item_ends) {                  // first chunk behind a contributing piece: its slab has drained, raise the counter
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_fetch_add(g_pw_sk_flags + t_j * 8 + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_fetch_add(p.split_sync + t_j * 8 + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             sk_signal_due = false;
         }
         if (item_ends) {
@@ -395,7 +394,7 @@ __global__ __launch_bounds__(512) void conv3x3_ppw_kernel(sp_conv_params p, int 
             bool run_epilogue = true;
             if (sk_signal_due) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_fetch_add(g_pw_sk_flags + t_j * 8 + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) __hip_atomic_fetch_add(p.split_sync + t_j * 8 + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 sk_signal_due = false;
             }
             // conv_pp.hip's hand-over on 128 registers per lane.  Written as three separate regions - stores | wait | a loop of loads whose
@@ -407,7 +406,7 @@ __global__ __launch_bounds__(512) void conv3x3_ppw_kernel(sp_conv_params p, int 
             int woff = wave * 8192 + lane;
             asm volatile("" : "+v"(woff));                               // (keeps the slab addresses out of the chunk loop's live ranges)
             float* slab0 = reinterpret_cast<float*>(p.workspace) + ((long)t_j * (sk_parts - 1)) * PW_SK_SLAB_FLOATS + woff;
-            int* flag = g_pw_sk_flags + t_j * 8 + wave;
+            int* flag = p.split_sync + t_j * 8 + wave;
             if (sk_give) {
                 float* dst = slab0 + (long)t_part * PW_SK_SLAB_FLOATS;
                 static_for<NFR>([&](auto gc_) {
@@ -567,7 +566,7 @@ __global__ __launch_bounds__(512) void conv3x3_ppw_kernel(sp_conv_params p, int 
     if (!half_b) __builtin_amdgcn_s_barrier();              // the barrier the other half passes after its last MFMA segment
     if (sk_signal_due) {                                    // (a contributing piece with no item behind it)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(g_pw_sk_flags + t_j * 8 + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_fetch_add(p.split_sync + t_j * 8 + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if constexpr (TIMING) {
         if (lane == 0 && p.workspace != nullptr) {
@@ -591,7 +590,7 @@ int launch_ppw(const sp_conv_params& p, int prio, hipStream_t s) {
     const int cotiles = (p.cout + G::CO_T - 1) / G::CO_T;
     const int total = p.n * (p.h / G::TH) * (p.w_ / G::TW) * cotiles;
     // persistent: one block per CU; the items of a last, partial round split along K where the caller lent the scratch
-    const PWSplit sk = pw_split_plan(total, (p.cin_p + G::KC - 1) / G::KC, (!TIMING && p.workspace != nullptr) ? p.workspace_bytes : 0);
+    const PWSplit sk = pw_split_plan(total, (p.cin_p + G::KC - 1) / G::KC, (!TIMING && p.workspace != nullptr && p.split_sync != nullptr) ? p.workspace_bytes : 0);
     sp_note_route("conv3x3_ppw<16bit> (64 co x 4 rows per wave)");
     hipLaunchKernelGGL(kern, dim3((unsigned)sk.grid), dim3(512), G::LDS, s, p, cotiles, total, prio, sk.parts);
     SP_LAUNCH_CHECK();

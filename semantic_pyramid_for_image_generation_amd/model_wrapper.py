@@ -400,6 +400,13 @@ class ModelWrapper(object):
             st["announced"] = None             # (tensor, version) whose pyramid st["feats_real"] holds, if a caller announced it
         handed_over = self._vgg_ahead      # the eager iteration in front of this capture announced its successor
         self._vgg_ahead = None
+        # the zero-at-rest counters of the convolution kernels' K-split (ops._split_sync) are per stream: create the capture stream's
+        # area BEFORE the capture, so that its zero fill is not a node of every replay
+        if torch.cuda.graph.default_capture_stream is None:
+            torch.cuda.graph.default_capture_stream = torch.cuda.Stream()
+        with torch.cuda.stream(torch.cuda.graph.default_capture_stream):
+            ops._split_sync(images_real.device)
+        torch.cuda.synchronize()
         self._capturing = True
         try:
             gd = torch.cuda.CUDAGraph()

@@ -791,6 +791,20 @@ def conv_pool_idx_ok(n: int, h: int, w: int, cin_p: int, cout: int, dtype) -> bo
     return (conv_pool2_ok(h, w, cout, 3) and cout % 16 == 0 and n * h * w * cin_p * esz < (1 << 30) and cout * 9 * cin_p * esz < (1 << 30))
 
 
+# sp_conv_params.split_sync: the zero-at-rest counters of the 3x3 kernels' K-split of their last partial round - one area per
+# (device, stream), so that launches on different streams never share one (include/sempyr.h); allocated on first use (inside a graph
+# capture: from the graph's pool, its zero fill captured with it)
+_SPLIT_SYNC = {}
+
+
+def _split_sync(device) -> torch.Tensor:
+    key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
+    t = _SPLIT_SYNC.get(key)
+    if t is None:
+        t = _SPLIT_SYNC[key] = torch.zeros(L.SP_CONV_SPLIT_SYNC_BYTES // 4, dtype=torch.int32, device=device)
+    return t
+
+
 def _conv_launch(x, w_ptr: int, bias, y, res1, res2, mask_src, slope: float, n, h, w, cin_p, cout, ldy, ksize, act,
                  dtype, pool2: bool = False, in_up2: bool = False, img_scale: int = 0, img_split: int = 0, pool_idx=None) -> None:
     """img_scale: device ADDRESS of the two per-group accumulator scales of a two-group batch (include/sempyr.h), 0 = none."""
@@ -814,6 +828,8 @@ def _conv_launch(x, w_ptr: int, bias, y, res1, res2, mask_src, slope: float, n, 
         if ws_bytes:
             ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
             p.workspace, p.workspace_bytes = ws.data_ptr(), ws_bytes
+            if dtype != torch.float32:
+                p.split_sync = _split_sync(x.device).data_ptr()
     L.call("sp_conv2d_igemm", ctypes.byref(p), stream())
 
 

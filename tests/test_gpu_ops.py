@@ -283,6 +283,40 @@ def test_conv3x3_pingpong_tail_split_bf16(case):
     _tail_split_case(case)
 
 
+def test_conv3x3_tail_split_on_two_streams_bf16():
+    """The K-split keeps its counters in the CALLER's zero-at-rest area, one per stream (sp_conv_params.split_sync; the library has no
+    device-side state): two streams launching split convolutions at the same time get what one stream gets."""
+    dt = torch.bfloat16
+    g = torch.Generator(device="cuda").manual_seed(31)
+    n, cin, cout, hw = 20, 256, 256, 64                                   # 640 items: R = 128, two pieces
+    xs = [ops.nhwc_empty(n, cin, hw, hw, dt, "cuda").normal_(generator=g) for _ in range(2)]
+    ws = [(torch.randn(cout, 3, 3, cin, device="cuda", generator=g) * 0.05).to(dt) for _ in range(2)]
+
+    def launch(i, y):
+        ops._conv_launch(xs[i], ws[i].data_ptr(), None, y, None, None, None, 0.2, n, hw, hw, cin, cout, cout, 3, 1, dt)
+    ref = []
+    for i in range(2):
+        y = ops.nhwc_empty(n, cout, hw, hw, dt, "cuda")
+        launch(i, y)
+        ref.append(y)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[], []]
+    for rep in range(6):
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                y = ops.nhwc_empty(n, cout, hw, hw, dt, "cuda").fill_(-3.0)
+                launch(i, y)
+                outs[i].append(y)
+    torch.cuda.synchronize()
+    assert len({k for k in ops._SPLIT_SYNC if k[1] in (streams[0].cuda_stream, streams[1].cuda_stream)}) == 2
+    for i in range(2):
+        for y in outs[i]:
+            assert torch.equal(y, ref[i]), i
+    for t in ops._SPLIT_SYNC.values():
+        assert int(t.abs().sum()) == 0                                    # every launch left its counters clean
+
+
 PPW_SPLIT_CASES = [  # the same for conv_ppw.hip's 16-row items (forced: SP_TUNE_CONV_PPW = 2): (n, cin, cout, h, w, act, res, mask, pool2, up, bias, groups)
     (20, 256, 256, 64, 64, 1, 1, False, 0, False, True, False),     # 320 items: R = 64
     (40, 512, 512, 32, 32, 0, 2, False, 0, False, True, True),      # 320, two groups, 16 chunks
