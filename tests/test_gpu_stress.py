@@ -169,6 +169,44 @@ def test_ping_pong_kernels_random_shapes(seed):
     assert not fails, fails
 
 
+@pytest.mark.parametrize("dt,seed,ppw", [(torch.bfloat16, 0, 1), (torch.bfloat16, 7, 2), (torch.float16, 2, 1), (torch.float16, 4, 2)])
+def test_tail_split_random_shapes_beyond_one_round(dt, seed, ppw):
+    """Round 6: launches of MORE than one round of the 256 persistent blocks with a partial last round (the K-split of conv_pp.hip and,
+    with SP_TUNE_CONV_PPW = 2, of conv_ppw.hip): random batch / map / channel counts with 257 ... 1200 work items, partial K chunks
+    and channel tiles, every epilogue operand, both 16-bit storage types; each case twice into dirty outputs, against fp32 arithmetic."""
+    _seed(seed)
+    ops.set_compute_dtype(dt)
+    fails, split_like = [], 0
+    ops.set_tuning(L.TUNE_KEYS["SP_CONV_PPW"], ppw)
+    try:
+        for _ in range(28):
+            cout = random.choice([128, 256, 192, 136, 320, 64, 48])
+            cin = random.choice([64, 72, 128, 136, 256, 264, 512])
+            h, w = 16 * random.randint(1, 4), 32 * random.randint(1, 2)
+            rows = 16 if (cout <= 64 or ppw == 2) else 8
+            per = (h // rows) * (w // 32) * ((cout + 127) // 128)
+            items = random.randint(257, 1200)
+            n = max(1, min(48, (items + per - 1) // per))
+            if n * h * w * max(cin, cout) > 6e7:
+                continue
+            split_like += (n * per) % 256 != 0 and n * per > 256
+            pool2 = random.choice([0, 0, 0, 1, 2]) if cout % 16 == 0 and cout > 32 else 0
+            act = random.choice([0, 1, 2] if pool2 == 0 else [0, 2])
+            res = random.choice([0, 0, 1, 2]) if pool2 != 2 else 0
+            mask = random.random() < 0.25 and pool2 == 0
+            bias = random.random() < 0.8
+            up = cout > 32 and pool2 == 0 and random.random() < 0.2
+            e = _conv_case(dt, n, cin, cout, 3, h, w, act, res, mask, pool2, bias, up)
+            if e > (8e-3 if dt == torch.bfloat16 else 2e-3):
+                fails.append((n, cin, cout, h, w, act, res, mask, pool2, bias, up, e))
+    finally:
+        ops.set_tuning(L.TUNE_KEYS["SP_CONV_PPW"], -1)
+    assert not fails, fails
+    assert split_like >= 12, split_like
+    for t in ops._SPLIT_SYNC.values():
+        assert int(t.abs().sum()) == 0           # the counters are clean after every launch
+
+
 @pytest.mark.parametrize("dt,seed", [(torch.bfloat16, 0), (torch.bfloat16, 5), (torch.float16, 1)])
 def test_four_row_wave_kernel_random_shapes(dt, seed):
     """conv_ppw.hip forced onto every launch it covers (SP_TUNE_CONV_PPW = 2): random channel counts (partial K chunks: 72, 136, 264;
