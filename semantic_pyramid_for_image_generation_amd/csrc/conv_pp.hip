@@ -66,7 +66,8 @@ struct PPSplit { int parts, tail_items, grid; };
 // tail_items * parts blocks of one piece each (SP_TUNE_CONV_PP_SPLIT = 2 keeps the split to launches of at least one full round).
 inline PPSplit pp_split_plan(int total, int kchunks, long workspace_bytes) {
     PPSplit r{0, 0, total < PP_NUM_CU ? total : PP_NUM_CU};
-    if (r.grid >= 8) r.grid -= r.grid % 8;                 // (the XCD remap of the round-robin items wants a multiple of 8)
+    // (less than one round: one block per item - rounded down to a multiple of 8 for the XCD remap, 100 items became 96 blocks of
+    // which four took two items, i.e. two rounds; the kernels skip the remap when the grid is not a multiple of 8)
     const int mode = sp_tune(SP_TUNE_CONV_PP_SPLIT, 1);
     if (!mode || total <= 0 || (total < PP_NUM_CU && mode == 2)) return r;
     const int R = total % PP_NUM_CU;

@@ -41,7 +41,8 @@ constexpr int PW_SK_SLAB_FLOATS = 8 * 64 * 128;
 struct PWSplit { int parts, tail_items, grid; };
 inline PWSplit pw_split_plan(int total, int kchunks, long workspace_bytes) {
     PWSplit r{0, 0, total < PW_NUM_CU ? total : PW_NUM_CU};
-    if (r.grid >= 8) r.grid -= r.grid % 8;
+    // (less than one round: one block per item - rounded down to a multiple of 8 for the XCD remap, 100 items became 96 blocks of
+    // which four took two items, i.e. two rounds; the kernels skip the remap when the grid is not a multiple of 8)
     const int mode = sp_tune(SP_TUNE_CONV_PP_SPLIT, 1);
     if (!mode || total <= 0 || (total < PW_NUM_CU && mode == 2)) return r;
     const int R = total % PW_NUM_CU;
