@@ -82,7 +82,9 @@ int sp_version(void);
  *   SP_TUNE_BN_ITERS         pixels per thread of the elementwise BatchNorm passes (grid sizing; default 2)
  *   SP_TUNE_CONV_PP_SPLIT    0 = the ping-pong 3x3 kernels never split the work items of their last, partial round along K (default 1: they
  *                            do where sp_conv_params.workspace holds the partial tiles - sp_conv2d_workspace() says how many bytes - and
- *                            sp_conv_params.split_sync the counters; 2 = only launches of at least one full round of the 256 blocks)
+ *                            sp_conv_params.split_sync the counters; 2 = only launches of at least one full round of the 256 blocks; 3 (tests) = like
+ *                            1, and the closing piece of an item stores and counts like every other piece - the hand-over's re-read
+ *                            path, which otherwise runs only when a block is delayed, on every split launch)
  *   SP_TUNE_CONV_PP_PRIO     bit 0: s_setprio 1 around every MFMA segment of the ping-pong kernel (default 1); bit 1: static priority 1
  *                            for the second-dispatched half of the block */
 enum { SP_TUNE_CONV_TALL = 0, SP_TUNE_IGEMM_DMA = 1, SP_TUNE_WGRAD_ROWS = 2, SP_TUNE_DETERMINISTIC = 3,

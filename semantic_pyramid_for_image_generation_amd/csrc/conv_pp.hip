@@ -45,18 +45,20 @@ constexpr int PP_BIAS_MAX = 1024;              // output channels whose bias fit
 // The block is persistent with one block per CU, so a launch takes ceil(items / 256) rounds: 320 items (512 -> 512 on 32 x 32 maps at
 // batch 20) cost two rounds with 3/4 of the chip idle in the second; at the metric's batch of 20 most mid-network layers sit at 1.25 /
 // 2.5 rounds, which batch 32 does not (profiles/README.md, round 6).  With sk_parts = P > 1 the R = items mod 256 items of the last round
-// are cut into P pieces along K (P = min(4, 256 / R) consecutive ranges of channel chunks) and piece q of tail item j goes to the block
-// with the physical index j * P + q - the DMA stream runs into a piece like into any other item.  Pieces q < P - 1 are their block's
-// FIRST piece of work: they leave their raw fp32 accumulators in a slab of the caller's workspace (sp_conv_params.workspace) - stores
-// that drain while the block's first full item computes - and at the end of that item the wave raises a per-(item, wave) counter
-// (behind `s_waitcnt vmcnt(0)`: the stores are at the memory side).  Piece P - 1 is its block's LAST piece of work (and the highest
-// block index of the item, so every block it depends on was dispatched before it): it finds the counter raised a whole item ago, adds
-// the slabs in piece order (a fixed order: the result does not depend on timing) and runs the item's ordinary epilogue.  (A first
-// version ran every piece last: the owner then waits for store -> signal -> load round trips at the very end of the launch, 10 - 20
-// us, more than the split saves below K = 512.)  Slabs and counters move with agent-scope relaxed atomics (sc1: through the XCD's L2 to
-// the memory side - the L2s of different XCDs are not coherent for plain accesses); the waiter zeroes the counter again, so the
-// counters (sp_conv_params.split_sync: the caller's zero-at-rest area, one per stream - the library keeps no device state) are clean
-// whenever no launch is in flight.
+// are cut into P pieces along K (consecutive ranges of channel chunks; P from a cost model, pp_split_plan) and piece q of tail item j
+// goes to the block with the physical index j * P + q - the DMA stream runs into a piece like into any other item.  Pieces q < P - 1 are
+// their block's FIRST piece of work, piece P - 1 its block's LAST.  The hand-over is WAIT-FREE: a piece stores its raw fp32
+// accumulators in its own slab of the caller's scratch (sp_conv_params.workspace), lets them land (`s_waitcnt vmcnt(0)`) and raises a
+// per-(item, wave) counter; the wave that raises it LAST adds the P slabs in a fixed order (results do not depend on timing) and
+// runs the item's ordinary epilogue - normally the closing piece, which arrives an item after the others, finds the counter full
+// and keeps its own accumulators in registers.  Nobody ever waits for another block: a version in which the closing piece spun on
+// the counter was 0.5 us per launch faster (the early pieces raised their counters one chunk later, off the critical path) and
+// DEADLOCKED when two processes shared one GPU - each kernel's spinning blocks kept the other's not-yet-dispatched pieces off the
+// CUs (tests/test_gpu_two_ranks.py hung).  (Before that, every piece ran LAST in its block: store -> signal -> load round trips at the
+// very end of the launch, 10 - 20 us, more than the split saves below K = 512.)  Slabs and counters move with agent-scope relaxed
+// atomics (sc1: through the XCD's L2 to the memory side - the L2s of different XCDs are not coherent for plain accesses); the wave that
+// runs the epilogue zeroes the counter again, so the counters (sp_conv_params.split_sync: the caller's zero-at-rest area, one per
+// stream - the library keeps no device state) are clean whenever no launch is in flight.
 constexpr int PP_SK_MAX_PARTS = 4;
 constexpr int PP_SK_SLAB_FLOATS = 8 * 64 * 64;           // one piece: 8 waves x 64 lanes x 64 accumulator registers = 128 KB
 
@@ -84,7 +86,7 @@ inline PPSplit pp_split_plan(int total, int kchunks, long workspace_bytes) {
         const long c = 37L * ((kchunks + q - 1) / q) + handover * (q - 1);
         if (c < best && 20 * c < 19 * 37L * kchunks) { best = c; P = q; }
     }
-    if (P < 2 || (long)R * (P - 1) * PP_SK_SLAB_FLOATS * 4 > workspace_bytes) return r;
+    if (P < 2 || (long)R * P * PP_SK_SLAB_FLOATS * 4 > workspace_bytes) return r;
     r.parts = P; r.tail_items = R;
     r.grid = total < PP_NUM_CU ? R * P : PP_NUM_CU;
     return r;
@@ -129,7 +131,9 @@ constexpr int pp_group_index(int h, int dr, int rw) {
 // 18 K instructions in ~1 100 basic blocks around a 1.7 K-instruction loop; measured with compile-time assumptions in its place
 // (scratch: -DPP_ASSUME_SIMPLE), a launch of 128->128 @128^2 drops from 170 K to 148 K cycles per block, 64->128 from 111 K to 92 K.
 template <typename T, int WCO, int PRIO, bool TIMING = false, bool DMA_IN_L = true, bool FAST = false, int FW = 2, bool TAIL = false, bool IDX = false>
-__global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int cotiles, int total, int prio, int sk_parts) {
+__global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int cotiles, int total, int prio, int sk_arg) {
+    const int sk_parts = sk_arg & 255;                      // pieces per tail item (0 / 1: no split); bit 8: the closing piece does not peek (tests)
+    const bool sk_peek = !(sk_arg & 256);
     static_assert(!IDX || (!FAST && sizeof(T) == 2), "pool_idx: the general 16-bit epilogue");
     static_assert(!TAIL || (FAST && WCO == 1 && FW == 2), "the fused 1x1 tail lives in the 64-channel FAST form");
     using G = PPGeom<T, WCO, FW>;
@@ -248,7 +252,6 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
     bool cur_is_tail, nxt_is_tail;
     cur = item_coords(0, cur_is_tail);
     nxt = item_coords(1, nxt_is_tail);
-    bool sk_signal_due = false;                             // a contributing piece whose stores are in flight
     auto set_halo_desc = [&](const Coords& c) {
         const int n = c.n, ty0 = c.ty_i * TH, tx0 = c.tx_i * PP_TW;
         int l4 = lane >> 2;
@@ -454,13 +457,6 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
         stage(std::integral_constant<int, 0>{});
         stage(std::integral_constant<int, 1>{});
         stage(std::integral_constant<int, 2>{});
-        if (sk_signal_due && !item_ends) {
-            // the first chunk behind a contributing piece: its slab stores were issued three stages ago - raise the counter now (an
-            // owner with a single full item in front of its piece asks for it one item after this block started)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_fetch_add(p.split_sync + t_j * 8 + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sk_signal_due = false;
-        }
         if (item_ends) {
             // BOTH epilogues in one barrier interval.  After its last MFMA segment the leading half passes the barrier, runs its
             // epilogue and the next item's first LOAD segment; the other half is in its last MFMA segment meanwhile and would then
@@ -472,19 +468,21 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
             const int co_b = co0 + wco * 64 + (lane >> 4) * 16;          // this lane's 16 consecutive channels
             const bool wide = FAST ? co_b < p.cout : vec_ok && (p.ldy & 7) == 0 && co_b + 16 <= p.cout;
             bool run_epilogue = true;
-            if (sk_signal_due) {                                         // the item behind a contributing piece: its slab has had a whole item to drain
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_fetch_add(p.split_sync + t_j * 8 + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sk_signal_due = false;
-            }
             if (cur_is_tail && sk_parts > 1) {                           // wave-uniform
-                // tail split: pieces 0 .. P - 2 hand their raw accumulators over, piece P - 1 adds them (in piece order) and goes on
+                // tail split, WAIT-FREE: nobody ever waits for another block (two kernels that spin for blocks of their own which the
+                // other one keeps off the CUs deadlock - seen with two ranks sharing one GPU).  A piece stores its raw accumulators in
+                // ITS slab, lets the stores land (vmcnt(0)) and raises the item's per-wave counter; whoever raises it last sums the P
+                // slabs in the fixed order P - 1, 0, 1, ..., P - 2 and runs the epilogue.  The closing piece (P - 1, its block's last
+                // work) looks first: with every other piece in it keeps its accumulators (the usual case - the others arrived an item
+                // ago), which is that same order.
                 int woff = wave * 4096 + lane;
                 asm volatile("" : "+v"(woff));                           // (computed HERE: hoisted out of the chunk loop, the sixty-odd
                                                                          // addresses below stay live across it and spill)
-                float* slab0 = reinterpret_cast<float*>(p.workspace) + ((long)t_j * (sk_parts - 1)) * PP_SK_SLAB_FLOATS + woff;
+                float* slab0 = reinterpret_cast<float*>(p.workspace) + ((long)t_j * sk_parts) * PP_SK_SLAB_FLOATS + woff;
                 int* flag = p.split_sync + t_j * 8 + wave;
-                if (!t_owner) {
+                bool fast = false, last = false;
+                if (t_owner && sk_peek) fast = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sk_parts - 1;
+                if (!fast) {
                     float* dst = slab0 + (long)t_part * PP_SK_SLAB_FLOATS;
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
@@ -493,27 +491,33 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
                                 __hip_atomic_store(dst + ((i * NFR + j) * 4 + r) * 64, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    sk_signal_due = true;                                // raised at the end of the next item (or of the block)
-                    run_epilogue = false;
-                } else {
-                    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sk_parts - 1) __builtin_amdgcn_s_sleep(8);
-                    asm volatile("" ::: "memory");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the slab is at the memory side before the counter says so
+                    int old = 0;
+                    if (lane == 0) old = __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    last = __builtin_amdgcn_readfirstlane(old) == sk_parts - 1;
+                }
+                run_epilogue = fast || last;
+                // slabs to add, in order: the closing piece's own (kept in registers on the fast path, re-read otherwise), then 0 .. P - 2
+                const int q_first = fast ? 0 : -1, q_end = run_epilogue ? sk_parts - 1 : -1;
 #pragma unroll 1
-                    for (int q = 0; q < sk_parts - 1; ++q) {
-                        const float* src = slab0 + (long)q * PP_SK_SLAB_FLOATS;
-                        // all 64 loads of a slab in flight: one round trip to the memory side per slab (the stage's fragment registers are
-                        // free here; two trips of 32 cost the owner of a four-piece item 12 us)
-                        f32x4_t t[4 * NFR];                              // whole fragments: the accumulators are 4-register tuples (element-wise
-                                                                         // updates cost conv_ppw.hip, with its 128 accumulators, 300 spilled registers)
+                for (int q = q_first; q < q_end; ++q) {
+                    const float* src = slab0 + (long)(q < 0 ? sk_parts - 1 : q) * PP_SK_SLAB_FLOATS;
+                    // all 64 loads of a slab in flight: one round trip to the memory side per slab; whole fragments (the accumulators are
+                    // 4-register tuples: element-wise updates cost conv_ppw.hip, with its 128 accumulators, 300 spilled registers)
+                    f32x4_t t[4 * NFR];
 #pragma unroll
-                        for (int k = 0; k < NFR * 16; ++k)
-                            t[k >> 2][k & 3] = __hip_atomic_load(src + k * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int k = 0; k < NFR * 16; ++k)
+                        t[k >> 2][k & 3] = __hip_atomic_load(src + k * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (q < 0) {
+#pragma unroll
+                        for (int f = 0; f < 4 * NFR; ++f) acc[f / NFR][f % NFR] = t[f];
+                    } else {
 #pragma unroll
                         for (int f = 0; f < 4 * NFR; ++f) acc[f / NFR][f % NFR] += t[f];
-                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    if (lane == 0) __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next launch
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+                if (run_epilogue && lane == 0) __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next launch
             }
             if (run_epilogue) {
             if (up) {                                                    // the 1/4 of the average-pooling gradient
@@ -777,10 +781,6 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(sp_conv_params p, int c
         }
     }
     if (!half_b) __builtin_amdgcn_s_barrier();              // the barrier the other half passes after its last MFMA segment
-    if (sk_signal_due) {                                    // (a contributing piece with no item behind it)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(p.split_sync + t_j * 8 + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     if constexpr (G::F8) {
         // one atomic per BLOCK on the running maximum (per item and wave they serialise on one L2 word: 10 K atomics = 100+ us)
         if (p.y8_amax != nullptr) {
@@ -830,7 +830,8 @@ int launch_pp(const sp_conv_params& p, int prio, hipStream_t s) {
     const int grid = sk.grid;
     sp_note_route(G::F8 ? "conv3x3_pp<f8,2>" : FW == 1 ? "conv3x3_pp<16bit,2,FAST,w16>" : WCO == 2 ? (FAST ? "conv3x3_pp<16bit,2,FAST>" : "conv3x3_pp<16bit,2>")
                                                                                   : (FAST ? "conv3x3_pp<16bit,1,FAST>" : "conv3x3_pp<16bit,1>"));
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), LDS_BYTES, s, p, cotiles, total, prio, sk.parts);
+    // SP_TUNE_CONV_PP_SPLIT = 3 (tests): the closing piece stores and counts like every other piece, so the re-read order runs on every split launch
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), LDS_BYTES, s, p, cotiles, total, prio, sk.parts | (sp_tune(SP_TUNE_CONV_PP_SPLIT, 1) == 3 ? 256 : 0));
     SP_LAUNCH_CHECK();
     return SP_OK;
 }
@@ -845,7 +846,7 @@ long sp_conv_pp_split_workspace(int n, int h, int w, int cin_p, int cout) {
     auto plan = [&](long total) {
         if (total >= (1L << 30)) return;
         const PPSplit sk = pp_split_plan((int)total, kchunks, 1L << 40);
-        const long b = (long)sk.tail_items * (sk.parts > 1 ? sk.parts - 1 : 0) * PP_SK_SLAB_FLOATS * 4;
+        const long b = (long)sk.tail_items * (sk.parts > 1 ? sk.parts : 0) * PP_SK_SLAB_FLOATS * 4;
         if (b > need) need = b;
     };
     if (cout <= 64) { if (h % 16 == 0) plan((long)n * (h / 16) * (w / PP_TW_WIDE)); }
@@ -857,7 +858,7 @@ long sp_conv_pp_split_workspace(int n, int h, int w, int cin_p, int cout) {
 long sp_conv_pp_split_workspace_w16(int n, int h, int cin_p, int cout) {
     if (h % 16 != 0 || cout <= 64 || (long)n * (h / 16) * ((cout + 127) / 128) < 64) return 0;      // (sp_conv_pp_launch's admission)
     const PPSplit sk = pp_split_plan(n * (h / 16) * ((cout + 127) / 128), (cin_p + 31) / 32, 1L << 40);
-    return (long)sk.tail_items * (sk.parts > 1 ? sk.parts - 1 : 0) * PP_SK_SLAB_FLOATS * 4;
+    return (long)sk.tail_items * (sk.parts > 1 ? sk.parts : 0) * PP_SK_SLAB_FLOATS * 4;
 }
 
 // dispatch(): what a launch of `total` 8-row items costs, in hundredths of the time of one item on every CU - whole rounds without the

@@ -56,7 +56,7 @@ inline PWSplit pw_split_plan(int total, int kchunks, long workspace_bytes) {
         const long c = 67L * ((kchunks + q - 1) / q) + handover * (q - 1);
         if (c < best && 20 * c < 19 * 67L * kchunks) { best = c; P = q; }
     }
-    if (P < 2 || (long)R * (P - 1) * PW_SK_SLAB_FLOATS * 4 > workspace_bytes) return r;
+    if (P < 2 || (long)R * P * PW_SK_SLAB_FLOATS * 4 > workspace_bytes) return r;
     r.parts = P; r.tail_items = R;
     r.grid = total < PW_NUM_CU ? R * P : PW_NUM_CU;
     return r;
@@ -78,7 +78,9 @@ struct PWGeom {
 };
 
 template <typename T, bool TIMING = false, bool DMA_LB = true, bool POOL = false>
-__global__ __launch_bounds__(512) void conv3x3_ppw_kernel(sp_conv_params p, int cotiles, int total, int prio, int sk_parts) {
+__global__ __launch_bounds__(512) void conv3x3_ppw_kernel(sp_conv_params p, int cotiles, int total, int prio, int sk_arg) {
+    const int sk_parts = sk_arg & 255;                      // (conv_pp.hip: pieces per tail item; bit 8: the closing piece does not peek)
+    const bool sk_peek = !(sk_arg & 256);
     static_assert(sizeof(T) == 2, "16-bit storage");
     using G = PWGeom<T>;
     constexpr int E = G::E, KC = G::KC, CO_T = G::CO_T, WPX = G::WPX, RW = G::RW, FW = G::FW, NB = G::NB, NFR = G::NFR, HR = G::HR, HP = G::HP, TH = G::TH;
@@ -175,7 +177,6 @@ __global__ __launch_bounds__(512) void conv3x3_ppw_kernel(sp_conv_params p, int 
     bool cur_is_tail, nxt_is_tail;
     cur = item_coords(0, cur_is_tail);
     nxt = item_coords(1, nxt_is_tail);
-    bool sk_signal_due = false;
     auto set_halo_desc = [&](const Coords& c) {
         const int n = c.n, ty0 = c.ty_i * TH, tx0 = c.tx_i * PW_TW;
         int l4 = lane >> 2;
@@ -382,33 +383,26 @@ __global__ __launch_bounds__(512) void conv3x3_ppw_kernel(sp_conv_params p, int 
         stage(std::integral_constant<int, 0>{});
         stage(std::integral_constant<int, 1>{});
         stage(std::integral_constant<int, 2>{});
-        if (sk_signal_due && !item_ends) {                  // first chunk behind a contributing piece: its slab has drained, raise the counter
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_fetch_add(p.split_sync + t_j * 8 + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sk_signal_due = false;
-        }
         if (item_ends) {
             const int n = cur.n, ty0 = cur.ty_i * TH, tx0 = cur.tx_i * PW_TW, co0 = cur.co_i * CO_T;
             const long pix0 = ((long)n * H + ty0 + RW * wpx) * W + tx0 + (lane & 15);
             const int co_b = co0 + wco * 64 + (lane >> 4) * 16;          // this lane's 16 consecutive channels
             const bool wide = co_b < p.cout;
             bool run_epilogue = true;
-            if (sk_signal_due) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_fetch_add(p.split_sync + t_j * 8 + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sk_signal_due = false;
-            }
-            // conv_pp.hip's hand-over on 128 registers per lane.  Written as three separate regions - stores | wait | a loop of loads whose
-            // trip count is zero for everyone but the owner - and sixteen registers per group behind an opaque offset: as one
-            // if / else the two paths (accumulators unchanged / accumulators updated) met in 128 phi copies and the main loop of this
-            // kernel (~245 registers) spilled 300
+            // conv_pp.hip's WAIT-FREE hand-over on 128 registers per lane: store the own slab, raise the counter, and whoever raises it
+            // last sums the P slabs in the order P - 1, 0, ..., P - 2 and runs the epilogue; the closing piece looks first and keeps
+            // its accumulators if everybody else is in.  Written as separate regions - stores | counter | ONE loop of loads whose trip
+            // count is zero for everyone else - and sixteen registers per group behind an opaque offset, whole-fragment updates: as
+            // an if / else the two paths (accumulators unchanged / updated) met in 128 phi copies and the main loop of this kernel
+            // (~245 registers) spilled 300
             const bool sk_tail = cur_is_tail && sk_parts > 1;           // wave-uniform
-            const bool sk_give = sk_tail && !t_owner, sk_take = sk_tail && t_owner;
             int woff = wave * 8192 + lane;
             asm volatile("" : "+v"(woff));                               // (keeps the slab addresses out of the chunk loop's live ranges)
-            float* slab0 = reinterpret_cast<float*>(p.workspace) + ((long)t_j * (sk_parts - 1)) * PW_SK_SLAB_FLOATS + woff;
+            float* slab0 = reinterpret_cast<float*>(p.workspace) + ((long)t_j * sk_parts) * PW_SK_SLAB_FLOATS + woff;
             int* flag = p.split_sync + t_j * 8 + wave;
-            if (sk_give) {
+            bool sk_fast = false, sk_last = false;
+            if (sk_tail && t_owner && sk_peek) sk_fast = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sk_parts - 1;
+            if (sk_tail && !sk_fast) {
                 float* dst = slab0 + (long)t_part * PW_SK_SLAB_FLOATS;
                 static_for<NFR>([&](auto gc_) {
                     constexpr int g = decltype(gc_)::value;               // accumulators 16 g .. 16 g + 15 = acc[g / 2][4 (g % 2) .. + 3][0..3]
@@ -419,17 +413,17 @@ __global__ __launch_bounds__(512) void conv3x3_ppw_kernel(sp_conv_params p, int 
                         __hip_atomic_store(dst + o + k * 64, acc[g / 2][4 * (g % 2) + (k >> 2)][k & 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __builtin_amdgcn_sched_barrier(0);
                 });
-                sk_signal_due = true;
-                run_epilogue = false;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the slab is at the memory side before the counter says so
+                int old = 0;
+                if (lane == 0) old = __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sk_last = __builtin_amdgcn_readfirstlane(old) == sk_parts - 1;
             }
-            if (sk_take) {
-                while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sk_parts - 1) __builtin_amdgcn_s_sleep(8);
-                asm volatile("" ::: "memory");
-            }
-            const int sk_slabs = sk_take ? sk_parts - 1 : 0;
+            if (sk_tail) run_epilogue = sk_fast || sk_last;
+            const int sk_q0 = sk_fast ? 0 : -1, sk_q1 = (sk_tail && run_epilogue) ? sk_parts - 1 : -1;
 #pragma unroll 1
-            for (int q = 0; q < sk_slabs; ++q) {
-                const float* src = slab0 + (long)q * PW_SK_SLAB_FLOATS;
+            for (int q = sk_q0; q < sk_q1; ++q) {
+                const float* src = slab0 + (long)(q < 0 ? sk_parts - 1 : q) * PW_SK_SLAB_FLOATS;
+                const bool replace = q < 0;                              // first slab of the re-read order REPLACES the accumulators
                 static_for<NFR>([&](auto gc_) {
                     constexpr int g = decltype(gc_)::value;
                     int o = g * 16 * 64;
@@ -438,11 +432,14 @@ __global__ __launch_bounds__(512) void conv3x3_ppw_kernel(sp_conv_params p, int 
 #pragma unroll
                     for (int k = 0; k < 16; ++k) t[k >> 2][k & 3] = __hip_atomic_load(src + o + k * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-                    for (int f = 0; f < 4; ++f) acc[g / 2][4 * (g % 2) + f] += t[f];
+                    for (int f = 0; f < 4; ++f) {
+                        const f32x4_t sum = acc[g / 2][4 * (g % 2) + f] + t[f];
+                        acc[g / 2][4 * (g % 2) + f] = replace ? t[f] : sum;   // (a select on a uniform condition: bit for bit the slab)
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 });
             }
-            if (sk_take && lane == 0) __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (sk_tail && run_epilogue && lane == 0) __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (run_epilogue) {
             if (up) {                                                    // the 1/4 of the average-pooling gradient
 #pragma unroll
@@ -565,10 +562,6 @@ __global__ __launch_bounds__(512) void conv3x3_ppw_kernel(sp_conv_params p, int 
         }
     }
     if (!half_b) __builtin_amdgcn_s_barrier();              // the barrier the other half passes after its last MFMA segment
-    if (sk_signal_due) {                                    // (a contributing piece with no item behind it)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(p.split_sync + t_j * 8 + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     if constexpr (TIMING) {
         if (lane == 0 && p.workspace != nullptr) {
             float* out = reinterpret_cast<float*>(p.workspace) + ((long)blockIdx.x * 8 + wave) * 16;
@@ -593,7 +586,7 @@ int launch_ppw(const sp_conv_params& p, int prio, hipStream_t s) {
     // persistent: one block per CU; the items of a last, partial round split along K where the caller lent the scratch
     const PWSplit sk = pw_split_plan(total, (p.cin_p + G::KC - 1) / G::KC, (!TIMING && p.workspace != nullptr && p.split_sync != nullptr) ? p.workspace_bytes : 0);
     sp_note_route("conv3x3_ppw<16bit> (64 co x 4 rows per wave)");
-    hipLaunchKernelGGL(kern, dim3((unsigned)sk.grid), dim3(512), G::LDS, s, p, cotiles, total, prio, sk.parts);
+    hipLaunchKernelGGL(kern, dim3((unsigned)sk.grid), dim3(512), G::LDS, s, p, cotiles, total, prio, sk.parts | (sp_tune(SP_TUNE_CONV_PP_SPLIT, 1) == 3 ? 256 : 0));
     SP_LAUNCH_CHECK();
     return SP_OK;
 }
@@ -615,7 +608,7 @@ long sp_conv_ppw_split_workspace(int n, int h, int w, int cin_p, int cout) {
     const long total = (long)n * (h / 16) * (w / 32) * ((cout + 127) / 128);
     if (total >= (1L << 30)) return 0;
     const PWSplit sk = pw_split_plan((int)total, (cin_p + 31) / 32, 1L << 40);
-    return (long)sk.tail_items * (sk.parts > 1 ? sk.parts - 1 : 0) * PW_SK_SLAB_FLOATS * 4;
+    return (long)sk.tail_items * (sk.parts > 1 ? sk.parts : 0) * PW_SK_SLAB_FLOATS * 4;
 }
 
 // dispatch(): cost of `total` 16-row items in hundredths of ONE item's time on every CU (whole rounds without the split)

@@ -411,6 +411,16 @@ def _tail_split_case(case, want_route=None):
             assert float((d > 0).float().mean()) < 0.05, float((d > 0).float().mean())
         else:
             assert torch.equal(first, y1), (case, rep, int((first != y1).sum()))
+    # the hand-over's re-read path (the closing piece stores and counts like the others; otherwise only a delayed block takes it):
+    # the same bits as the usual path
+    ops.set_tuning(TUNE_CONV_PP_SPLIT, 3)
+    try:
+        for rep in range(2):
+            y3 = ops.nhwc_empty(n, cout, ho, wo, dt, "cuda").fill_(5.0)
+            launch(y3)
+            assert torch.equal(first, y3), (case, "re-read path", rep, int((first != y3).sum()))
+    finally:
+        ops.set_tuning(TUNE_CONV_PP_SPLIT, -1)
 
 
 PPW_CASES = [  # (n, cin, cout, h, w, act, residuals, mask, input-upsampled, bias, two groups, pool2)
