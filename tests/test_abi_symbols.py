@@ -85,3 +85,30 @@ def test_linear_split_rule_and_reduce_queue_host_side():
     assert lib.sp_wgrad_reduce_pending() == 0
     assert lib.sp_wgrad_reduce_defer(1) == 0 and lib.sp_wgrad_reduce_defer(0) == 0
     assert lib.sp_wgrad_reduce_flush(0, None) == 0 and lib.sp_wgrad_reduce_pending() == 0
+
+
+def test_conv_workspace_reports_the_tail_split_scratch():
+    """sp_conv2d_workspace (host logic, no GPU): 16-bit 3x3 layers on 32-pixel-wide maps get the scratch of the ping-pong kernels' K-split
+    of their last partial round - whole slabs (128 KB per piece of the 8-row kernel, 256 KB of the 16-row one), nothing where neither
+    kernel would split, nothing in the fp32 mode, nothing with SP_TUNE_CONV_PP_SPLIT = 0 (csrc/conv_pp.hip, conv_ppw.hip)."""
+    import torch
+    from semantic_pyramid_for_image_generation_amd import ops
+    slab = 128 * 1024
+    w = lambda n, h, w_, ci, co, dt=torch.bfloat16: ops.conv_workspace_bytes(n, h, w_, ci, co, 3, dt)      # noqa: E731
+    ops._CONV_WS_CACHE.clear()
+    a = w(20, 32, 32, 512, 512)          # 320 8-row items: 64 tail items x 4 pieces of 4 chunks
+    assert a == 64 * 4 * slab, a
+    assert w(20, 64, 64, 256, 256) == 128 * 2 * slab                     # 640 items: two pieces
+    assert w(20, 16, 16, 512, 512) == 80 * 3 * slab                      # less than a round on 16-wide tiles: 80 items x 3
+    assert w(40, 16, 16, 512, 512) == 0                                  # 160 items: no whole number of pieces fits
+    assert w(20, 128, 128, 64, 64) == 0                                  # 1280 16-row items of two chunks: exact rounds
+    assert w(20, 128, 128, 128, 128) % (2 * slab) == 0 and w(20, 128, 128, 128, 128) > 0      # the 16-row kernel's 640 items: 256 KB pieces
+    assert w(20, 32, 32, 512, 512, torch.float32) == 0
+    key = _lib.TUNE_KEYS["SP_CONV_PP_SPLIT"]
+    assert _lib.lib().sp_set_tuning(key, 0) == 0
+    try:
+        ops._CONV_WS_CACHE.clear()
+        assert w(20, 32, 32, 512, 512) == 0 and w(20, 16, 16, 512, 512) == 0
+    finally:
+        _lib.lib().sp_set_tuning(key, -1)
+        ops._CONV_WS_CACHE.clear()
